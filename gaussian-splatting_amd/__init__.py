@@ -1,0 +1,216 @@
+"""gaussian-splatting_amd — host-side Python plumbing over libgsx.so.
+
+The product is the C-ABI library built from csrc/ (include/gsx.h); this module is
+a thin ctypes mirror used by tests and bench.py.  It never falls back to a CPU
+path: if libgsx.so is missing the import of `Gsx` raises.
+
+The directory name contains a hyphen (it mirrors the reference repo's name), so
+load it with `gsx_load()` from `__graft_entry__` / `tests/conftest.py` or via
+importlib; `import gaussian-splatting_amd` is not valid Python.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgsx.so")
+
+GSX_OK, GSX_E_INVALID, GSX_E_HIP, GSX_E_NOMEM, GSX_E_STATE, GSX_E_UNSUPPORTED, GSX_E_INTERNAL = 0, -1, -2, -3, -4, -5, -6
+
+# every symbol include/gsx.h declares
+ABI_SYMBOLS = [
+    "gsx_create", "gsx_destroy", "gsx_last_error", "gsx_sync", "gsx_set_profiling", "gsx_get_timings",
+    "gsx_upload_splats", "gsx_upload_splats_dev", "gsx_select_all", "gsx_select_list", "gsx_set_lod_octree",
+    "gsx_set_lod_hc", "gsx_select_octree", "gsx_select_hc", "gsx_get_selection", "gsx_sort", "gsx_get_sorted_dev",
+    "gsx_get_keys", "gsx_render", "gsx_get_framebuffer_dev",
+]
+
+
+class Uniforms(C.Structure):
+    """gsx_uniforms (reference main.cpp:48-58), 224 bytes."""
+    _fields_ = [("projectionMatrix", C.c_float * 16), ("viewMatrix", C.c_float * 16), ("modelMatrix", C.c_float * 16),
+                ("splatSize", C.c_float), ("cutOff", C.c_float), ("fov", C.c_float), ("bayerSize", C.c_uint32),
+                ("bayerScale", C.c_float), ("padding", C.c_float * 3)]
+
+
+class OctreeFlat(C.Structure):
+    _fields_ = [("n_nodes", C.c_uint32), ("center3", C.c_void_p), ("half3", C.c_void_p), ("parent", C.c_void_p),
+                ("is_leaf", C.c_void_p)]
+
+
+class HcFlat(C.Structure):
+    _fields_ = [("n_nodes", C.c_uint32), ("parent", C.c_void_p), ("is_leaf", C.c_void_p), ("error", C.c_void_p),
+                ("weight", C.c_void_p)]
+
+
+class Timings(C.Structure):
+    _fields_ = [("select_ms", C.c_float), ("keygen_ms", C.c_float), ("sort_ms", C.c_float), ("project_ms", C.c_float),
+                ("bin_ms", C.c_float), ("raster_ms", C.c_float), ("total_ms", C.c_float), ("sort_passes", C.c_uint32),
+                ("sort_launches", C.c_uint32), ("tile_pairs", C.c_uint64)]
+
+
+assert C.sizeof(Uniforms) == 224
+
+
+def make_uniforms(proj, view, model=None, splatSize=1.0, cutOff=3.5, fov=45.0, bayerSize=1, bayerScale=1.0):
+    u = Uniforms()
+    model = np.eye(4, dtype=np.float32).reshape(-1) if model is None else model
+    for name, m in (("projectionMatrix", proj), ("viewMatrix", view), ("modelMatrix", model)):
+        arr = np.ascontiguousarray(m, dtype=np.float32).reshape(-1)
+        C.memmove(getattr(u, name), arr.ctypes.data, 64)
+    u.splatSize, u.cutOff, u.fov, u.bayerSize, u.bayerScale = splatSize, cutOff, fov, bayerSize, bayerScale
+    return u
+
+
+class GsxError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"gsx error {code}: {msg}")
+        self.code = code
+
+
+def load_library(path=None):
+    """dlopen libgsx.so.  Raises (never falls back) when the HIP library is absent."""
+    path = path or LIB_PATH
+    if not os.path.exists(path):
+        raise ImportError(f"{path} not found: build it with `make -C {os.path.join(_HERE, 'csrc')}` "
+                          "(or __graft_entry__.build()); there is no CPU fallback")
+    lib = C.CDLL(path)
+    lib.gsx_last_error.restype = C.c_char_p
+    lib.gsx_last_error.argtypes = [C.c_void_p]
+    return lib
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class Gsx:
+    """One context per GPU (include/gsx.h)."""
+
+    def __init__(self, device=0, lib=None):
+        self.lib = lib or load_library()
+        self.ctx = C.c_void_p()
+        rc = self.lib.gsx_create(C.c_int(device), C.byref(self.ctx))
+        if rc != GSX_OK:
+            raise GsxError(rc, "gsx_create failed (no usable HIP device?)")
+        self.n = 0
+        self._keep = []
+
+    def _chk(self, rc):
+        if rc != GSX_OK:
+            raise GsxError(rc, self.lib.gsx_last_error(self.ctx).decode())
+
+    def close(self):
+        if self.ctx:
+            self.lib.gsx_destroy(self.ctx)
+            self.ctx = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # -- scene --
+    def upload(self, splats):
+        splats = np.ascontiguousarray(splats, np.float32).reshape(-1, 20)
+        self._chk(self.lib.gsx_upload_splats(self.ctx, _ptr(splats), C.c_uint64(splats.shape[0])))
+        self.n = splats.shape[0]
+
+    def upload_dev(self, dev_ptr, n):
+        self._chk(self.lib.gsx_upload_splats_dev(self.ctx, C.c_void_p(dev_ptr), C.c_uint64(n)))
+        self.n = n
+
+    # -- selection --
+    def select_all(self):
+        self._chk(self.lib.gsx_select_all(self.ctx))
+
+    def select_list(self, idx):
+        idx = np.ascontiguousarray(idx, np.uint32)
+        self._chk(self.lib.gsx_select_list(self.ctx, _ptr(idx), C.c_uint32(len(idx))))
+
+    def set_lod_octree(self, center3, half3, parent, is_leaf):
+        arrs = [np.ascontiguousarray(center3, np.float32), np.ascontiguousarray(half3, np.float32),
+                np.ascontiguousarray(parent, np.uint32), np.ascontiguousarray(is_leaf, np.uint8)]
+        t = OctreeFlat(len(arrs[2]), *[a.ctypes.data for a in arrs])
+        self._chk(self.lib.gsx_set_lod_octree(self.ctx, C.byref(t)))
+
+    def set_lod_hc(self, parent, is_leaf, error, weight):
+        arrs = [np.ascontiguousarray(parent, np.uint32), np.ascontiguousarray(is_leaf, np.uint8),
+                np.ascontiguousarray(error, np.float32), np.ascontiguousarray(weight, np.float32)]
+        t = HcFlat(len(arrs[0]), *[a.ctypes.data for a in arrs])
+        self._chk(self.lib.gsx_set_lod_hc(self.ctx, C.byref(t)))
+
+    def select_octree(self, viewproj, min_screen_area, want_count=True):
+        vp = np.ascontiguousarray(viewproj, np.float32)
+        m = C.c_uint32(0)
+        self._chk(self.lib.gsx_select_octree(self.ctx, _ptr(vp), C.c_float(min_screen_area), C.byref(m) if want_count else None))
+        return m.value
+
+    def select_hc(self, cam_pos, threshold, want_count=True):
+        cam = np.ascontiguousarray(cam_pos, np.float32)
+        m = C.c_uint32(0)
+        self._chk(self.lib.gsx_select_hc(self.ctx, _ptr(cam), C.c_float(threshold), C.byref(m) if want_count else None))
+        return m.value
+
+    def selection(self):
+        m = C.c_uint32(0)
+        self._chk(self.lib.gsx_get_selection(self.ctx, None, C.c_uint32(0), C.byref(m)))
+        out = np.empty(m.value, np.uint32)
+        self._chk(self.lib.gsx_get_selection(self.ctx, _ptr(out), C.c_uint32(len(out)), C.byref(m)))
+        return out
+
+    # -- sort --
+    def sort(self, cam_pos, download=True):
+        cam = np.ascontiguousarray(cam_pos, np.float32)
+        if not download:
+            self._chk(self.lib.gsx_sort(self.ctx, _ptr(cam), None))
+            return None
+        out = np.empty(max(self.n, 1), np.uint32)
+        self._chk(self.lib.gsx_sort(self.ctx, _ptr(cam), _ptr(out)))
+        dev = C.c_void_p()
+        m = C.c_uint32(0)
+        self._chk(self.lib.gsx_get_sorted_dev(self.ctx, C.byref(dev), C.byref(m)))
+        return out[:m.value].copy()
+
+    def sorted_dev(self):
+        dev = C.c_void_p()
+        m = C.c_uint32(0)
+        self._chk(self.lib.gsx_get_sorted_dev(self.ctx, C.byref(dev), C.byref(m)))
+        return dev.value, m.value
+
+    def keys(self, cam_pos):
+        cam = np.ascontiguousarray(cam_pos, np.float32)
+        out = np.empty(max(self.n, 1), np.float32)
+        self._chk(self.lib.gsx_get_keys(self.ctx, _ptr(cam), _ptr(out), C.c_uint32(len(out))))
+        m = C.c_uint32(0)
+        self._chk(self.lib.gsx_get_selection(self.ctx, None, C.c_uint32(0), C.byref(m)))
+        return out[:m.value].copy()
+
+    # -- render --
+    def render(self, uniforms, width, height, y0=0, y1=None, download=True, out=None):
+        y1 = height if y1 is None else y1
+        if download and out is None:
+            out = np.zeros((height, width, 4), np.uint8)
+        self._chk(self.lib.gsx_render(self.ctx, C.byref(uniforms), C.c_uint32(width), C.c_uint32(height), C.c_uint32(y0),
+                                      C.c_uint32(y1), _ptr(out) if download else None))
+        return out
+
+    def framebuffer_dev(self):
+        dev = C.c_void_p()
+        w, h = C.c_uint32(0), C.c_uint32(0)
+        self._chk(self.lib.gsx_get_framebuffer_dev(self.ctx, C.byref(dev), C.byref(w), C.byref(h)))
+        return dev.value, w.value, h.value
+
+    # -- misc --
+    def sync(self):
+        self._chk(self.lib.gsx_sync(self.ctx))
+
+    def set_profiling(self, on=True):
+        self._chk(self.lib.gsx_set_profiling(self.ctx, C.c_int(1 if on else 0)))
+
+    def timings(self):
+        t = Timings()
+        self._chk(self.lib.gsx_get_timings(self.ctx, C.byref(t)))
+        return {f[0]: getattr(t, f[0]) for f in Timings._fields_}

@@ -1,0 +1,402 @@
+// gsx_api.hip — the extern "C" entry points declared in include/gsx.h.
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "gsx_internal.h"
+
+uint64_t gsx_sort_workspace_bytes(uint64_t cap);
+
+namespace {
+
+template <typename T>
+int dev_alloc(gsx_ctx* c, T** p, uint64_t count) {
+    if (*p) { GSX_HIP(c, hipFree(*p)); *p = nullptr; }
+    if (count == 0) count = 1;
+    GSX_HIP(c, hipMalloc(reinterpret_cast<void**>(p), count * sizeof(T)));
+    return GSX_OK;
+}
+
+template <typename T>
+void dev_free(T** p) {
+    if (*p) { (void)hipFree(*p); *p = nullptr; }
+}
+
+int set_device(gsx_ctx* c) {
+    GSX_HIP(c, hipSetDevice(c->device));
+    return GSX_OK;
+}
+
+// Reads the device flag block (synchronises the stream).
+int check_flags(gsx_ctx* c) {
+    GSX_HIP(c, hipMemcpyAsync(c->flags_host, c->flags, sizeof(GsxDevFlags), hipMemcpyDeviceToHost, c->stream));
+    GSX_HIP(c, hipStreamSynchronize(c->stream));
+    if (c->flags_host->spin_expired) { c->err = "device: bounded look-back spin expired (results invalid)"; return GSX_E_INTERNAL; }
+    if (c->flags_host->pair_overflow) { c->err = "device: tile pair buffer overflow"; return GSX_E_INTERNAL; }
+    if (c->flags_host->pad) { c->err = "selection list holds an id >= n"; return GSX_E_INVALID; }
+    return GSX_OK;
+}
+
+int alloc_scene(gsx_ctx* c, uint64_t n) {
+    int rc;
+    if ((rc = dev_alloc(c, &c->pos4, n)) || (rc = dev_alloc(c, &c->covA, n)) || (rc = dev_alloc(c, &c->covB, n)) ||
+        (rc = dev_alloc(c, &c->color4, n)))
+        return rc;
+    if ((rc = dev_alloc(c, &c->sel_idx, n))) return rc;
+    c->sel_cap = n;
+    for (int b = 0; b < 2; ++b)
+        if ((rc = dev_alloc(c, &c->keys[b], n)) || (rc = dev_alloc(c, &c->vals[b], n))) return rc;
+    c->sort_cap = n;
+    c->sort_zero_bytes = gsx_sort_workspace_bytes(n);
+    {
+        uint8_t* z = reinterpret_cast<uint8_t*>(c->sort_zero);
+        if ((rc = dev_alloc(c, &z, c->sort_zero_bytes))) return rc;
+        c->sort_zero = reinterpret_cast<GsxSortZero*>(z);
+    }
+    if ((rc = dev_alloc(c, &c->proj, n))) return rc;
+    c->proj_cap = n;
+    // LOD / list-selection scratch (flags padded for 16-byte vector loads)
+    const uint64_t fl = (n + 15) / 16 * 16 + 16;
+    if ((rc = dev_alloc(c, &c->lod_stop, fl)) || (rc = dev_alloc(c, &c->lod_emit, fl))) return rc;
+    if ((rc = dev_alloc(c, &c->lod_block_sums, n / 4096 + 2))) return rc;
+    c->lod_cap = n;
+    return GSX_OK;
+}
+
+float ev_ms(gsx_ctx* c, int a, int b) {
+    float ms = 0.0f;
+    if (hipEventElapsedTime(&ms, c->ev[a], c->ev[b]) != hipSuccess) return 0.0f;
+    return ms;
+}
+
+}  // namespace
+
+extern "C" {
+
+int gsx_create(int device, gsx_ctx** out) {
+    if (!out) return GSX_E_INVALID;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) return GSX_E_HIP;
+    gsx_ctx* c = new (std::nothrow) gsx_ctx();
+    if (!c) return GSX_E_NOMEM;
+    c->device = device;
+    auto fail = [&](int rc) { gsx_destroy(c); return rc; };
+    if (hipSetDevice(device) != hipSuccess) return fail(GSX_E_HIP);
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return fail(GSX_E_HIP);
+    for (int i = 0; i < EV_COUNT; ++i)
+        if (hipEventCreate(&c->ev[i]) != hipSuccess) return fail(GSX_E_HIP);
+    if (hipMalloc(reinterpret_cast<void**>(&c->m_dev), 16) != hipSuccess) return fail(GSX_E_NOMEM);
+    if (hipMalloc(reinterpret_cast<void**>(&c->pair_total_dev), 16) != hipSuccess) return fail(GSX_E_NOMEM);
+    if (hipMalloc(reinterpret_cast<void**>(&c->plan), sizeof(GsxSortPlan)) != hipSuccess) return fail(GSX_E_NOMEM);
+    if (hipMalloc(reinterpret_cast<void**>(&c->flags), sizeof(GsxDevFlags)) != hipSuccess) return fail(GSX_E_NOMEM);
+    if (hipHostMalloc(reinterpret_cast<void**>(&c->plan_host), sizeof(GsxSortPlan), hipHostMallocDefault) != hipSuccess)
+        return fail(GSX_E_NOMEM);
+    if (hipHostMalloc(reinterpret_cast<void**>(&c->flags_host), sizeof(GsxDevFlags), hipHostMallocDefault) != hipSuccess)
+        return fail(GSX_E_NOMEM);
+    if (hipMemset(c->flags, 0, sizeof(GsxDevFlags)) != hipSuccess) return fail(GSX_E_HIP);
+    if (hipMemset(c->m_dev, 0, 16) != hipSuccess) return fail(GSX_E_HIP);
+    if (hipMemset(c->plan, 0, sizeof(GsxSortPlan)) != hipSuccess) return fail(GSX_E_HIP);
+    *out = c;
+    return GSX_OK;
+}
+
+int gsx_destroy(gsx_ctx* c) {
+    if (!c) return GSX_E_INVALID;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    dev_free(&c->pos4); dev_free(&c->covA); dev_free(&c->covB); dev_free(&c->color4);
+    dev_free(&c->sel_idx); dev_free(&c->m_dev);
+    dev_free(&c->lod_a); dev_free(&c->lod_b); dev_free(&c->lod_parent); dev_free(&c->lod_leaf);
+    dev_free(&c->lod_stop); dev_free(&c->lod_emit); dev_free(&c->lod_block_sums);
+    for (int b = 0; b < 2; ++b) { dev_free(&c->keys[b]); dev_free(&c->vals[b]); dev_free(&c->pair_key[b]); dev_free(&c->pair_val[b]); }
+    dev_free(&c->sort_zero); dev_free(&c->plan); dev_free(&c->flags);
+    dev_free(&c->proj); dev_free(&c->splat_ntiles); dev_free(&c->scan_block_sums);
+    dev_free(&c->tile_start); dev_free(&c->pair_total_dev); dev_free(&c->fb);
+    if (c->bin_zero) { (void)hipFree(c->bin_zero); c->bin_zero = nullptr; }
+    if (c->plan_host) (void)hipHostFree(c->plan_host);
+    if (c->flags_host) (void)hipHostFree(c->flags_host);
+    for (int i = 0; i < EV_COUNT; ++i)
+        if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return GSX_OK;
+}
+
+const char* gsx_last_error(const gsx_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+int gsx_sync(gsx_ctx* c) {
+    if (!c) return GSX_E_INVALID;
+    int rc = set_device(c);
+    if (rc) return rc;
+    return check_flags(c);
+}
+
+int gsx_set_profiling(gsx_ctx* c, int enabled) {
+    if (!c) return GSX_E_INVALID;
+    c->profiling = enabled != 0;
+    return GSX_OK;
+}
+
+int gsx_get_timings(gsx_ctx* c, gsx_timings* out) {
+    if (!c || !out) return GSX_E_INVALID;
+    int rc = set_device(c);
+    if (rc) return rc;
+    GSX_HIP(c, hipStreamSynchronize(c->stream));
+    gsx_timings t = c->tim;
+    if (c->profiling) {
+        if (c->ev_recorded[EV_SEL1]) t.select_ms = ev_ms(c, EV_SEL0, EV_SEL1);
+        if (c->ev_recorded[EV_SORT1]) {
+            t.keygen_ms = ev_ms(c, EV_KEY0, EV_KEY1);
+            t.sort_ms = ev_ms(c, EV_KEY1, EV_SORT1);
+        }
+        if (c->ev_recorded[EV_RAST1]) {
+            t.project_ms = ev_ms(c, EV_PROJ0, EV_PROJ1);
+            t.bin_ms = ev_ms(c, EV_PROJ1, EV_BIN1);
+            t.raster_ms = ev_ms(c, EV_BIN1, EV_RAST1);
+        }
+        t.total_ms = t.select_ms + t.keygen_ms + t.sort_ms + t.project_ms + t.bin_ms + t.raster_ms;
+    }
+    if (c->sorted_valid) {
+        GSX_HIP(c, hipMemcpy(c->plan_host, c->plan, 64, hipMemcpyDeviceToHost));
+        t.sort_passes = c->plan_host->passes_run;
+        t.sort_launches = GSX_PASSES;
+    }
+    *out = t;
+    return GSX_OK;
+}
+
+static int upload_common(gsx_ctx* c, const void* aos_dev, uint64_t n) {
+    int rc;
+    if ((rc = alloc_scene(c, n))) return rc;
+    c->n = n;
+    GSX_HIP(c, hipMemsetAsync(c->flags, 0, sizeof(GsxDevFlags), c->stream));
+    if ((rc = gsx_launch_upload(c, aos_dev, n))) return rc;
+    c->lod_kind = 0;
+    c->sorted_valid = false;
+    if ((rc = gsx_select_all(c))) return rc;
+    GSX_HIP(c, hipMemcpyAsync(c->flags_host, c->flags, sizeof(GsxDevFlags), hipMemcpyDeviceToHost, c->stream));
+    GSX_HIP(c, hipStreamSynchronize(c->stream));
+    if (c->flags_host->asym_cov) {
+        c->err = "splat covariance block (transform 3x3) is not symmetric";
+        c->n = 0;
+        return GSX_E_UNSUPPORTED;
+    }
+    return GSX_OK;
+}
+
+int gsx_upload_splats(gsx_ctx* c, const void* aos80_host, uint64_t n) {
+    if (!c || (!aos80_host && n) || n > 0x7FFFFFF0ull) return GSX_E_INVALID;
+    int rc = set_device(c);
+    if (rc) return rc;
+    void* staging = nullptr;
+    if (n) {
+        GSX_HIP(c, hipMalloc(&staging, n * 80));
+        hipError_t e = hipMemcpyAsync(staging, aos80_host, n * 80, hipMemcpyHostToDevice, c->stream);
+        if (e != hipSuccess) { (void)hipFree(staging); c->err = hipGetErrorString(e); return GSX_E_HIP; }
+    }
+    rc = upload_common(c, staging, n);
+    (void)hipStreamSynchronize(c->stream);
+    if (staging) (void)hipFree(staging);
+    return rc;
+}
+
+int gsx_upload_splats_dev(gsx_ctx* c, const void* aos80_dev, uint64_t n) {
+    if (!c || (!aos80_dev && n) || n > 0x7FFFFFF0ull) return GSX_E_INVALID;
+    int rc = set_device(c);
+    if (rc) return rc;
+    return upload_common(c, aos80_dev, n);
+}
+
+int gsx_select_all(gsx_ctx* c) {
+    if (!c) return GSX_E_INVALID;
+    int rc = set_device(c);
+    if (rc) return rc;
+    c->sel_iota = true;
+    c->m_cap = static_cast<uint32_t>(c->n);
+    c->sorted_valid = false;
+    const uint32_t m = c->m_cap;
+    GSX_HIP(c, hipMemcpyAsync(c->m_dev, &m, 4, hipMemcpyHostToDevice, c->stream));
+    GSX_HIP(c, hipStreamSynchronize(c->stream));  // &m is a stack word
+    return GSX_OK;
+}
+
+int gsx_select_list(gsx_ctx* c, const uint32_t* idx_host, uint32_t m) {
+    if (!c || (!idx_host && m)) return GSX_E_INVALID;
+    if (m > c->n) { c->err = "selection longer than the scene"; return GSX_E_INVALID; }
+    int rc = set_device(c);
+    if (rc) return rc;
+    if (m) GSX_HIP(c, hipMemcpyAsync(c->vals[0], idx_host, static_cast<uint64_t>(m) * 4, hipMemcpyHostToDevice, c->stream));
+    if ((rc = gsx_launch_sort_list(c, m))) return rc;
+    c->sel_iota = false;
+    c->m_cap = m;
+    c->sorted_valid = false;
+    return check_flags(c);  // also makes idx_host reusable
+}
+
+int gsx_set_lod_octree(gsx_ctx* c, const gsx_octree_flat* t) {
+    if (!c || !t || !t->center3 || !t->half3 || !t->parent || !t->is_leaf) return GSX_E_INVALID;
+    if (t->n_nodes != c->n) { c->err = "octree: node count must equal splat count (node i owns splat i)"; return GSX_E_INVALID; }
+    int rc = set_device(c);
+    if (rc) return rc;
+    const uint32_t n = t->n_nodes;
+    for (uint32_t i = 0; i < n; ++i)
+        if (t->parent[i] != 0xFFFFFFFFu && t->parent[i] >= i) { c->err = "octree: parent must precede child (BFS order)"; return GSX_E_INVALID; }
+    std::vector<float> a(static_cast<size_t>(n) * 4), b(static_cast<size_t>(n) * 4);
+    for (uint32_t i = 0; i < n; ++i) {
+        a[4 * i + 0] = t->center3[3 * i + 0]; a[4 * i + 1] = t->center3[3 * i + 1]; a[4 * i + 2] = t->center3[3 * i + 2];
+        a[4 * i + 3] = t->half3[3 * i + 0];
+        b[4 * i + 0] = t->half3[3 * i + 1]; b[4 * i + 1] = t->half3[3 * i + 2]; b[4 * i + 2] = 0; b[4 * i + 3] = 0;
+    }
+    if ((rc = dev_alloc(c, &c->lod_a, n)) || (rc = dev_alloc(c, &c->lod_b, n)) || (rc = dev_alloc(c, &c->lod_parent, n)) ||
+        (rc = dev_alloc(c, &c->lod_leaf, n)))
+        return rc;
+    GSX_HIP(c, hipMemcpy(c->lod_a, a.data(), static_cast<uint64_t>(n) * 16, hipMemcpyHostToDevice));
+    GSX_HIP(c, hipMemcpy(c->lod_b, b.data(), static_cast<uint64_t>(n) * 16, hipMemcpyHostToDevice));
+    GSX_HIP(c, hipMemcpy(c->lod_parent, t->parent, static_cast<uint64_t>(n) * 4, hipMemcpyHostToDevice));
+    GSX_HIP(c, hipMemcpy(c->lod_leaf, t->is_leaf, n, hipMemcpyHostToDevice));
+    c->lod_kind = 1;
+    c->lod_nodes = n;
+    return GSX_OK;
+}
+
+int gsx_set_lod_hc(gsx_ctx* c, const gsx_hc_flat* f) {
+    if (!c || !f || !f->parent || !f->is_leaf || !f->error || !f->weight) return GSX_E_INVALID;
+    if (f->n_nodes != c->n) { c->err = "hc: node count must equal splat count (node index == splat index)"; return GSX_E_INVALID; }
+    int rc = set_device(c);
+    if (rc) return rc;
+    const uint32_t n = f->n_nodes;
+    for (uint32_t i = 0; i < n; ++i)
+        if (f->parent[i] != 0xFFFFFFFFu && f->parent[i] >= n) { c->err = "hc: parent id out of range"; return GSX_E_INVALID; }
+    std::vector<float> a(static_cast<size_t>(n) * 4);
+    for (uint32_t i = 0; i < n; ++i) { a[4 * i] = f->error[i]; a[4 * i + 1] = f->weight[i]; a[4 * i + 2] = 0; a[4 * i + 3] = 0; }
+    if ((rc = dev_alloc(c, &c->lod_a, n)) || (rc = dev_alloc(c, &c->lod_parent, n)) || (rc = dev_alloc(c, &c->lod_leaf, n))) return rc;
+    GSX_HIP(c, hipMemcpy(c->lod_a, a.data(), static_cast<uint64_t>(n) * 16, hipMemcpyHostToDevice));
+    GSX_HIP(c, hipMemcpy(c->lod_parent, f->parent, static_cast<uint64_t>(n) * 4, hipMemcpyHostToDevice));
+    GSX_HIP(c, hipMemcpy(c->lod_leaf, f->is_leaf, n, hipMemcpyHostToDevice));
+    c->lod_kind = 2;
+    c->lod_nodes = n;
+    return GSX_OK;
+}
+
+static int finish_select(gsx_ctx* c, uint32_t* m_out) {
+    c->sel_iota = false;
+    c->m_cap = c->lod_nodes;
+    c->sorted_valid = false;
+    c->ev_recorded[EV_SEL1] = c->profiling;
+    if (m_out) {
+        GSX_HIP(c, hipMemcpyAsync(&c->plan_host->pad, c->m_dev, 4, hipMemcpyDeviceToHost, c->stream));
+        GSX_HIP(c, hipStreamSynchronize(c->stream));
+        *m_out = c->plan_host->pad;
+    }
+    return GSX_OK;
+}
+
+int gsx_select_octree(gsx_ctx* c, const float viewproj[16], float min_screen_area, uint32_t* m_out) {
+    if (!c || !viewproj) return GSX_E_INVALID;
+    if (c->lod_kind != 1) { c->err = "gsx_select_octree without gsx_set_lod_octree"; return GSX_E_STATE; }
+    int rc = set_device(c);
+    if (rc) return rc;
+    if ((rc = gsx_launch_select_octree(c, viewproj, min_screen_area))) return rc;
+    return finish_select(c, m_out);
+}
+
+int gsx_select_hc(gsx_ctx* c, const float cam_pos[3], float threshold, uint32_t* m_out) {
+    if (!c || !cam_pos) return GSX_E_INVALID;
+    if (c->lod_kind != 2) { c->err = "gsx_select_hc without gsx_set_lod_hc"; return GSX_E_STATE; }
+    int rc = set_device(c);
+    if (rc) return rc;
+    if ((rc = gsx_launch_select_hc(c, cam_pos, threshold))) return rc;
+    return finish_select(c, m_out);
+}
+
+int gsx_get_selection(gsx_ctx* c, uint32_t* idx_out, uint32_t capacity, uint32_t* m_out) {
+    if (!c || !m_out) return GSX_E_INVALID;
+    int rc = set_device(c);
+    if (rc) return rc;
+    GSX_HIP(c, hipMemcpyAsync(&c->plan_host->pad, c->m_dev, 4, hipMemcpyDeviceToHost, c->stream));
+    GSX_HIP(c, hipStreamSynchronize(c->stream));
+    const uint32_t m = c->plan_host->pad;
+    *m_out = m;
+    if (!idx_out) return GSX_OK;
+    if (capacity < m) { c->err = "selection buffer too small"; return GSX_E_INVALID; }
+    if (c->sel_iota) {
+        for (uint32_t i = 0; i < m; ++i) idx_out[i] = i;
+    } else if (m) {
+        GSX_HIP(c, hipMemcpy(idx_out, c->sel_idx, static_cast<uint64_t>(m) * 4, hipMemcpyDeviceToHost));
+    }
+    return GSX_OK;
+}
+
+int gsx_sort(gsx_ctx* c, const float cam_pos[3], uint32_t* idx_out_host) {
+    if (!c || !cam_pos) return GSX_E_INVALID;
+    int rc = set_device(c);
+    if (rc) return rc;
+    c->cam[0] = cam_pos[0]; c->cam[1] = cam_pos[1]; c->cam[2] = cam_pos[2];
+    if ((rc = gsx_launch_sort(c))) return rc;
+    c->ev_recorded[EV_SORT1] = c->profiling;
+    if (idx_out_host) {
+        GSX_HIP(c, hipMemcpyAsync(c->plan_host, c->plan, 64, hipMemcpyDeviceToHost, c->stream));
+        if ((rc = check_flags(c))) return rc;
+        const uint32_t m = c->plan_host->m;
+        if (m) GSX_HIP(c, hipMemcpy(idx_out_host, c->vals[c->plan_host->final_buf], static_cast<uint64_t>(m) * 4, hipMemcpyDeviceToHost));
+    }
+    return GSX_OK;
+}
+
+int gsx_get_sorted_dev(gsx_ctx* c, const uint32_t** idx_dev, uint32_t* m) {
+    if (!c || !idx_dev || !m) return GSX_E_INVALID;
+    if (!c->sorted_valid) { c->err = "no sorted permutation yet"; return GSX_E_STATE; }
+    int rc = set_device(c);
+    if (rc) return rc;
+    GSX_HIP(c, hipMemcpyAsync(c->plan_host, c->plan, 64, hipMemcpyDeviceToHost, c->stream));
+    if ((rc = check_flags(c))) return rc;
+    *idx_dev = c->vals[c->plan_host->final_buf];
+    *m = c->plan_host->m;
+    return GSX_OK;
+}
+
+int gsx_get_keys(gsx_ctx* c, const float cam_pos[3], float* dist_out_host, uint32_t capacity) {
+    if (!c || !cam_pos || !dist_out_host) return GSX_E_INVALID;
+    int rc = set_device(c);
+    if (rc) return rc;
+    if (capacity < c->m_cap) { c->err = "key buffer too small"; return GSX_E_INVALID; }
+    c->cam[0] = cam_pos[0]; c->cam[1] = cam_pos[1]; c->cam[2] = cam_pos[2];
+    c->sorted_valid = false;  // keys[0] doubles as scratch here
+    float* dev = reinterpret_cast<float*>(c->keys[0]);
+    if ((rc = gsx_launch_keys_only(c, dev))) return rc;
+    GSX_HIP(c, hipMemcpyAsync(&c->plan_host->pad, c->m_dev, 4, hipMemcpyDeviceToHost, c->stream));
+    GSX_HIP(c, hipStreamSynchronize(c->stream));
+    const uint32_t m = c->plan_host->pad;
+    if (m) GSX_HIP(c, hipMemcpy(dist_out_host, dev, static_cast<uint64_t>(m) * 4, hipMemcpyDeviceToHost));
+    return GSX_OK;
+}
+
+int gsx_render(gsx_ctx* c, const gsx_uniforms* u, uint32_t width, uint32_t height, uint32_t y0, uint32_t y1,
+               void* rgba8_out_host) {
+    if (!c || !u || width == 0 || height == 0 || y0 >= y1 || y1 > height) return GSX_E_INVALID;
+    if (width > 16384 || height > 16384) return GSX_E_INVALID;
+    if (!c->sorted_valid) { c->err = "gsx_render before gsx_sort"; return GSX_E_STATE; }
+    int rc = set_device(c);
+    if (rc) return rc;
+    if ((rc = gsx_launch_render(c, u, width, height, y0, y1))) return rc;
+    c->ev_recorded[EV_RAST1] = c->profiling;
+    if (rgba8_out_host) {
+        if ((rc = check_flags(c))) return rc;
+        const uint64_t row = static_cast<uint64_t>(width) * 4;
+        GSX_HIP(c, hipMemcpy(static_cast<uint8_t*>(rgba8_out_host) + y0 * row, c->fb + y0 * row, (y1 - y0) * row,
+                             hipMemcpyDeviceToHost));
+    }
+    return GSX_OK;
+}
+
+int gsx_get_framebuffer_dev(gsx_ctx* c, const void** rgba8_dev, uint32_t* width, uint32_t* height) {
+    if (!c || !rgba8_dev) return GSX_E_INVALID;
+    if (!c->fb) { c->err = "no frame rendered yet"; return GSX_E_STATE; }
+    *rgba8_dev = c->fb;
+    if (width) *width = c->fb_w;
+    if (height) *height = c->fb_h;
+    return GSX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,178 @@
+// gsx_internal.h — context layout and kernel launchers shared by the libgsx
+// translation units.  gfx950 (MI355X) only; wave = 64 lanes throughout.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+
+#include "../../include/gsx.h"
+
+#define GSX_WAVE 64
+#define GSX_RADIX 256
+#define GSX_PASSES 4
+
+// ---- sort geometry: one workgroup sorts one tile of NT*IPT keys per pass ----
+#define GSX_SORT_NT 256
+#define GSX_SORT_IPT 16
+#define GSX_SORT_TILE (GSX_SORT_NT * GSX_SORT_IPT)
+
+// ---- raster geometry ----
+#define GSX_TILE_W 16
+#define GSX_TILE_H 16
+
+// Device-resident plan of one sort, written by k_sort_plan and read by every
+// radix pass and by the consumers of the sorted permutation.
+struct GsxSortPlan {
+    uint32_t skip[GSX_PASSES];   // pass p copies nothing (all keys share digit p)
+    uint32_t src[GSX_PASSES];    // ping-pong buffer pass p reads (0/1)
+    uint32_t final_buf;          // buffer holding the sorted result
+    uint32_t m;                  // number of keys
+    uint32_t passes_run;
+    uint32_t pad;
+    uint32_t gbase[GSX_PASSES][GSX_RADIX];  // exclusive scan of the global digit histograms
+};
+
+// Small block zeroed by ONE hipMemsetAsync per sort; the look-back status words
+// follow it in the same allocation.
+struct GsxSortZero {
+    uint32_t ghist[GSX_PASSES][GSX_RADIX];
+    uint32_t tile_ctr[GSX_PASSES];
+    uint32_t pad[12];
+};
+
+// Error/diagnostic words written by kernels (never zeroed implicitly).
+struct GsxDevFlags {
+    uint32_t spin_expired;   // a bounded look-back spin ran out
+    uint32_t asym_cov;       // upload saw a non-symmetric covariance block
+    uint32_t pair_overflow;  // binner produced more pairs than the buffer holds
+    uint32_t pad;
+};
+
+// Projected splat record (48 B), written by k_project in ORIGINAL splat order.
+// Screen position of quad corner q in [-1,1]^2 is c + q.x*A + q.y*B (pixels);
+// m = cutOff * inverse([A B]) maps a pixel offset to the fragment's uv.
+struct GsxProj {
+    float cx, cy;             // centre in pixels
+    float ex, ey;             // half extents of the quad's pixel bbox (|A|+|B| per axis); ex < 0 = culled
+    float m00, m01, m10, m11; // u = m00*dx + m01*dy, v = m10*dx + m11*dy
+    float r, g, b, a;
+};
+
+struct gsx_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    bool profiling = false;
+
+    // scene (SoA in HBM)
+    uint64_t n = 0;
+    float4* pos4 = nullptr;    // transform[3] (x,y,z,w)
+    float4* covA = nullptr;    // s00 s01 s02 s11
+    float4* covB = nullptr;    // s12 s22 0 0
+    float4* color4 = nullptr;
+
+    // selection
+    bool sel_iota = true;
+    uint32_t m_cap = 0;        // host upper bound of the selection size
+    uint32_t* sel_idx = nullptr;   // ascending ids (capacity sel_cap)
+    uint64_t sel_cap = 0;
+    uint32_t* m_dev = nullptr;     // device word: selection size
+
+    // LOD structures
+    uint32_t lod_kind = 0;     // 0 none, 1 octree, 2 hc
+    uint32_t lod_nodes = 0;
+    float4* lod_a = nullptr;   // octree: (cx,cy,cz,hx) ; hc: (error, weight, 0, 0)
+    float4* lod_b = nullptr;   // octree: (hy,hz,0,0)
+    uint32_t* lod_parent = nullptr;
+    uint8_t* lod_leaf = nullptr;
+    uint8_t* lod_stop = nullptr;   // per-node "emit here if reached" predicate
+    uint8_t* lod_emit = nullptr;
+    uint32_t* lod_block_sums = nullptr;
+    uint64_t lod_cap = 0;
+
+    // sort
+    uint32_t* keys[2] = {nullptr, nullptr};
+    uint32_t* vals[2] = {nullptr, nullptr};
+    uint64_t sort_cap = 0;
+    GsxSortZero* sort_zero = nullptr;  // + status words behind it
+    uint64_t sort_zero_bytes = 0;
+    GsxSortPlan* plan = nullptr;
+    GsxSortPlan* plan_host = nullptr;  // pinned
+    bool sorted_valid = false;
+    float cam[3] = {0, 0, 0};
+
+    GsxDevFlags* flags = nullptr;
+    GsxDevFlags* flags_host = nullptr; // pinned
+
+    // raster
+    GsxProj* proj = nullptr;
+    uint64_t proj_cap = 0;
+    uint32_t* splat_ntiles = nullptr;  // per sorted rank: number of tiles touched, then its exclusive scan
+    uint32_t* scan_block_sums = nullptr;
+    uint64_t rank_cap = 0;
+    uint16_t* pair_key[2] = {nullptr, nullptr};
+    uint32_t* pair_val[2] = {nullptr, nullptr};
+    uint64_t pair_cap = 0;
+    uint32_t* tile_start = nullptr;    // n_tiles + 1
+    uint64_t tile_cap = 0;
+    uint32_t* pair_total_dev = nullptr;
+    uint8_t* fb = nullptr;             // RGBA8 width*height
+    uint64_t fb_cap = 0;
+    uint32_t fb_w = 0, fb_h = 0;
+    void* bin_zero = nullptr;          // zero block + status for the pair sort
+    uint64_t bin_zero_bytes = 0;
+
+    // timing
+    hipEvent_t ev[16] = {};
+    bool ev_recorded[16] = {};
+    gsx_timings tim = {};
+};
+
+enum GsxEvent {
+    EV_SEL0 = 0, EV_SEL1, EV_KEY0, EV_KEY1, EV_SORT1, EV_PROJ0, EV_PROJ1, EV_BIN1, EV_RAST1, EV_COUNT
+};
+
+#define GSX_HIP(ctx, call)                                                        \
+    do {                                                                          \
+        hipError_t e_ = (call);                                                   \
+        if (e_ != hipSuccess) {                                                   \
+            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);       \
+            return (e_ == hipErrorOutOfMemory) ? GSX_E_NOMEM : GSX_E_HIP;         \
+        }                                                                         \
+    } while (0)
+
+// ---- exactly rounded f32 arithmetic for the bit-exact paths (keys, LOD predicates) ----
+// HIP's __fmul_rn/__fadd_rn/__fsqrt_rn are NOT usable for this: unless OCML_BASIC_ROUNDED_OPERATIONS
+// is defined they expand to plain operators (open to FMA contraction) and to the approximate
+// native sqrt.  These helpers switch contraction off per function; sqrtf and '/' are correctly
+// rounded under hipcc's default -fhip-fp32-correctly-rounded-divide-sqrt.  gsx_sort.hip and
+// gsx_lod.hip are additionally compiled with -ffp-contract=off.
+#if defined(__HIPCC__)
+__device__ __forceinline__ float gsx_mul(float a, float b) {
+#pragma clang fp contract(off)
+    return a * b;
+}
+__device__ __forceinline__ float gsx_add(float a, float b) {
+#pragma clang fp contract(off)
+    return a + b;
+}
+__device__ __forceinline__ float gsx_sub(float a, float b) {
+#pragma clang fp contract(off)
+    return a - b;
+}
+__device__ __forceinline__ float gsx_div(float a, float b) { return a / b; }
+__device__ __forceinline__ float gsx_sqrt(float a) { return sqrtf(a); }
+#endif
+
+static inline uint32_t gsx_div_up(uint64_t a, uint64_t b) { return static_cast<uint32_t>((a + b - 1) / b); }
+
+// ---- launchers (defined in the .hip files) ----
+int gsx_launch_upload(gsx_ctx* c, const void* aos80_dev, uint64_t n);
+int gsx_launch_sort(gsx_ctx* c);                 // keygen + plan + radix passes on the current selection
+int gsx_launch_keys_only(gsx_ctx* c, float* dist_dev);
+int gsx_launch_iota_check(gsx_ctx* c);
+int gsx_launch_select_octree(gsx_ctx* c, const float vp[16], float thr);
+int gsx_launch_select_hc(gsx_ctx* c, const float cam[3], float thr);
+int gsx_launch_sort_list(gsx_ctx* c, uint32_t m); // ascending re-order of an explicit index list
+int gsx_launch_render(gsx_ctx* c, const gsx_uniforms* u, uint32_t w, uint32_t h, uint32_t y0, uint32_t y1);

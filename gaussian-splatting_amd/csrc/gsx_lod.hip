@@ -1,0 +1,214 @@
+// gsx_lod.hip — per-frame LOD cuts on flattened trees, producing the selection
+// (`indices`) as ASCENDING splat ids in HBM with its size in a device word.
+//
+// Reference path replaced: Octree::get_indices + BB::screen_area
+// (Octree.cpp:189-216, BB.hpp:41-77); HC::get_indices / GridHC::get_indices
+// (HC.cpp:100-132, GridHC.cpp:94-111).  The reference walks shared_ptr trees
+// breadth first on the CPU; here every node evaluates its own stop predicate,
+// then checks its ancestor chain, and a scan compacts the survivors.
+//
+//   emit[i] = stop[i]  &&  no ancestor a of i has stop[a]
+//   octree : stop = is_leaf || screen_area <  thr
+//   hc     : stop = is_leaf || error*weight*(1/dist^2) < thr
+//
+// All f32 arithmetic uses the gsx_mul/gsx_add/... helpers (one rounding per op, no
+// FMA contraction) in glm's operation order, so the index SETS are bit-identical to
+// the reference's.  The reference emits BFS/queue order; the sort's tie rule
+// needs ascending ids, which is what compaction yields.
+#include "gsx_internal.h"
+#include "gsx_onesweep.hpp"
+
+struct GsxMat4 { float m[16]; };
+
+// BB::screen_area (BB.hpp:59-77); clip = (m0*x + m1*y) + (m2*z + m3*1)
+// (glm/detail/type_mat4x4.inl:561-572); glm::min/max as ternaries.
+__device__ __forceinline__ float gsx_screen_area(float cx, float cy, float cz, float hx, float hy, float hz,
+                                                 const GsxMat4& vp) {
+    float mnx = 10000000.0f, mny = 10000000.0f, mxx = -10000000.0f, mxy = -10000000.0f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        // corner order BB.hpp:48-55: x sign = {-,+,+,-,-,+,+,-}, y = {-,-,+,+,-,-,+,+}, z = {-,-,-,-,+,+,+,+}
+        const bool xp = (i & 3) == 1 || (i & 3) == 2, yp = (i & 2) != 0, zp = (i & 4) != 0;
+        const float px = gsx_add(cx, xp ? hx : -hx), py = gsx_add(cy, yp ? hy : -hy), pz = gsx_add(cz, zp ? hz : -hz);
+        float clip[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (r == 2) continue;  // z is not used
+            const float a0 = gsx_add(gsx_mul(vp.m[0 + r], px), gsx_mul(vp.m[4 + r], py));
+            const float a1 = gsx_add(gsx_mul(vp.m[8 + r], pz), gsx_mul(vp.m[12 + r], 1.0f));
+            clip[r] = gsx_add(a0, a1);
+        }
+        if (clip[3] == 0.0f) continue;
+        const float nx = gsx_div(clip[0], clip[3]), ny = gsx_div(clip[1], clip[3]);
+        mnx = (nx < mnx) ? nx : mnx;
+        mny = (ny < mny) ? ny : mny;
+        mxx = (mxx < nx) ? nx : mxx;
+        mxy = (mxy < ny) ? ny : mxy;
+    }
+    return gsx_mul(gsx_sub(mxx, mnx), gsx_sub(mxy, mny));
+}
+
+__global__ __launch_bounds__(256) void k_octree_stop(const float4* __restrict__ a, const float4* __restrict__ b,
+                                                     const uint8_t* __restrict__ leaf, uint32_t n, GsxMat4 vp, float thr,
+                                                     uint8_t* __restrict__ stop) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 ca = a[i], cb = b[i];
+    const float area = gsx_screen_area(ca.x, ca.y, ca.z, ca.w, cb.x, cb.y, vp);
+    stop[i] = (leaf[i] || (area < thr)) ? 1 : 0;  // Octree.cpp:203
+}
+
+__global__ __launch_bounds__(256) void k_hc_stop(const float4* __restrict__ ew, const float4* __restrict__ pos4,
+                                                 const uint8_t* __restrict__ leaf, uint32_t n, float cx, float cy, float cz,
+                                                 float thr, uint8_t* __restrict__ stop) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 p = pos4[i], e = ew[i];
+    // HC.cpp:112-119: length(splat_pos - camera_pos); dist = 1/(d*d); metric = error*weight*dist
+    const float dx = gsx_sub(p.x, cx), dy = gsx_sub(p.y, cy), dz = gsx_sub(p.z, cz);
+    const float d = gsx_sqrt(gsx_add(gsx_add(gsx_mul(dx, dx), gsx_mul(dy, dy)), gsx_mul(dz, dz)));
+    const float dist = gsx_div(1.0f, gsx_mul(d, d));
+    const float metric = gsx_mul(gsx_mul(e.x, e.y), dist);
+    stop[i] = (metric < thr || leaf[i]) ? 1 : 0;  // HC.cpp:120
+}
+
+// emit[i] = stop[i] && no ancestor stops.  Chains are as deep as the tree; most
+// walks end after a step or two because an ancestor near the cut stops.
+__global__ __launch_bounds__(256) void k_emit_flags(const uint8_t* __restrict__ stop, const uint32_t* __restrict__ parent,
+                                                    uint32_t n, uint8_t* __restrict__ emit) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint8_t e = stop[i];
+    uint32_t a = parent[i];
+    while (e && a != 0xFFFFFFFFu) {
+        if (stop[a]) e = 0;
+        a = parent[a];
+    }
+    emit[i] = e;
+}
+
+// ---- flag compaction: emit bytes -> ascending id list + count ----
+#define GSX_CMP_NT 256
+#define GSX_CMP_IPT 16
+#define GSX_CMP_TILE (GSX_CMP_NT * GSX_CMP_IPT)
+
+__device__ __forceinline__ uint32_t gsx_load_flags16(const uint8_t* flags, uint32_t base, uint32_t n, uint32_t w[4]) {
+    // 16 flag bytes per thread; flags buffers are padded to a multiple of 16 bytes
+    uint32_t cnt = 0;
+    if (base < n) {
+        const uint4 v = *reinterpret_cast<const uint4*>(flags + base);
+        w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const bool on = ((w[j >> 2] >> (8 * (j & 3))) & 0xFFu) != 0 && (base + j) < n;
+            cnt += on ? 1u : 0u;
+        }
+    } else {
+        w[0] = w[1] = w[2] = w[3] = 0;
+    }
+    return cnt;
+}
+
+__global__ __launch_bounds__(GSX_CMP_NT) void k_compact_count(const uint8_t* __restrict__ flags, uint32_t n,
+                                                              uint32_t* __restrict__ block_sums) {
+    __shared__ uint32_t s_tmp[GSX_CMP_NT / 64];
+    uint32_t w[4];
+    const uint32_t base = blockIdx.x * GSX_CMP_TILE + threadIdx.x * GSX_CMP_IPT;
+    const uint32_t cnt = gsx_load_flags16(flags, base, n, w);
+    uint32_t total;
+    gsx_block_excl_scan<GSX_CMP_NT>(cnt, s_tmp, &total);
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
+}
+
+// single block: in-place exclusive scan of block_sums[0..nb), total -> *m_out
+__global__ __launch_bounds__(1024) void k_scan_block_sums(uint32_t* __restrict__ block_sums, uint32_t nb,
+                                                          uint32_t* __restrict__ m_out) {
+    __shared__ uint32_t s_tmp[1024 / 64];
+    __shared__ uint32_t s_carry;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < nb; base += 1024) {
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t v = (i < nb) ? block_sums[i] : 0u;
+        uint32_t total;
+        const uint32_t ex = gsx_block_excl_scan<1024>(v, s_tmp, &total);
+        const uint32_t carry = s_carry;
+        if (i < nb) block_sums[i] = carry + ex;
+        __syncthreads();
+        if (threadIdx.x == 0) s_carry = carry + total;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *m_out = s_carry;
+}
+
+__global__ __launch_bounds__(GSX_CMP_NT) void k_compact_write(const uint8_t* __restrict__ flags, uint32_t n,
+                                                              const uint32_t* __restrict__ block_offs,
+                                                              uint32_t* __restrict__ out) {
+    __shared__ uint32_t s_tmp[GSX_CMP_NT / 64];
+    uint32_t w[4];
+    const uint32_t base = blockIdx.x * GSX_CMP_TILE + threadIdx.x * GSX_CMP_IPT;
+    const uint32_t cnt = gsx_load_flags16(flags, base, n, w);
+    uint32_t pos = block_offs[blockIdx.x] + gsx_block_excl_scan<GSX_CMP_NT>(cnt, s_tmp, nullptr);
+    if (cnt == 0) return;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const bool on = ((w[j >> 2] >> (8 * (j & 3))) & 0xFFu) != 0 && (base + j) < n;
+        if (on) out[pos++] = base + j;
+    }
+}
+
+static int compact(gsx_ctx* c, uint32_t n) {
+    const uint32_t nb = gsx_div_up(n, GSX_CMP_TILE);
+    hipLaunchKernelGGL(k_compact_count, dim3(nb), dim3(GSX_CMP_NT), 0, c->stream, c->lod_emit, n, c->lod_block_sums);
+    hipLaunchKernelGGL(k_scan_block_sums, dim3(1), dim3(1024), 0, c->stream, c->lod_block_sums, nb, c->m_dev);
+    hipLaunchKernelGGL(k_compact_write, dim3(nb), dim3(GSX_CMP_NT), 0, c->stream, c->lod_emit, n, c->lod_block_sums,
+                       c->sel_idx);
+    GSX_HIP(c, hipGetLastError());
+    return GSX_OK;
+}
+
+int gsx_launch_select_octree(gsx_ctx* c, const float vp[16], float thr) {
+    const uint32_t n = c->lod_nodes;
+    GsxMat4 m;
+    for (int i = 0; i < 16; ++i) m.m[i] = vp[i];
+    if (c->profiling) GSX_HIP(c, hipEventRecord(c->ev[EV_SEL0], c->stream));
+    hipLaunchKernelGGL(k_octree_stop, dim3(gsx_div_up(n, 256)), dim3(256), 0, c->stream, c->lod_a, c->lod_b, c->lod_leaf, n,
+                       m, thr, c->lod_stop);
+    hipLaunchKernelGGL(k_emit_flags, dim3(gsx_div_up(n, 256)), dim3(256), 0, c->stream, c->lod_stop, c->lod_parent, n,
+                       c->lod_emit);
+    const int rc = compact(c, n);
+    if (c->profiling) GSX_HIP(c, hipEventRecord(c->ev[EV_SEL1], c->stream));
+    return rc;
+}
+
+int gsx_launch_select_hc(gsx_ctx* c, const float cam[3], float thr) {
+    const uint32_t n = c->lod_nodes;
+    if (c->profiling) GSX_HIP(c, hipEventRecord(c->ev[EV_SEL0], c->stream));
+    hipLaunchKernelGGL(k_hc_stop, dim3(gsx_div_up(n, 256)), dim3(256), 0, c->stream, c->lod_a, c->pos4, c->lod_leaf, n,
+                       cam[0], cam[1], cam[2], thr, c->lod_stop);
+    hipLaunchKernelGGL(k_emit_flags, dim3(gsx_div_up(n, 256)), dim3(256), 0, c->stream, c->lod_stop, c->lod_parent, n,
+                       c->lod_emit);
+    const int rc = compact(c, n);
+    if (c->profiling) GSX_HIP(c, hipEventRecord(c->ev[EV_SEL1], c->stream));
+    return rc;
+}
+
+// Explicit list -> ascending, duplicate-free selection: mark then compact.
+__global__ __launch_bounds__(256) void k_mark_list(const uint32_t* __restrict__ list, uint32_t m, uint32_t n,
+                                                   uint8_t* __restrict__ emit, GsxDevFlags* __restrict__ flags) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= m) return;
+    const uint32_t i = list[k];
+    if (i < n) emit[i] = 1;
+    else atomicOr(&flags->pad, 1u);  // out-of-range id
+}
+
+// `list` is a device staging copy of the caller's ids (c->vals[0] is free between sorts).
+int gsx_launch_sort_list(gsx_ctx* c, uint32_t m) {
+    const uint32_t n = static_cast<uint32_t>(c->n);
+    GSX_HIP(c, hipMemsetAsync(c->lod_emit, 0, (static_cast<uint64_t>(n) + 15) / 16 * 16, c->stream));
+    if (m > 0)
+        hipLaunchKernelGGL(k_mark_list, dim3(gsx_div_up(m, 256)), dim3(256), 0, c->stream, c->vals[0], m, n, c->lod_emit,
+                           c->flags);
+    return compact(c, n);
+}

@@ -1,0 +1,150 @@
+/*
+ * gsx.h — C ABI of libgsx.so: the MI355X (gfx950) implementation of the
+ * per-frame Gaussian-splat hot path of AllIAskOfYou/gaussian-splatting
+ *   LOD select -> depth keys -> view-ordered index sort -> projection ->
+ *   tile-binned alpha-blended rasterization.
+ *
+ * This is the drop-in boundary.  The reference has no FFI for this path: it is
+ * a set of C++ classes (SplatMesh / SplatMeshOctree / SplatMeshHC /
+ * SplatMeshGridHC, renderer.hpp).  The host-side C++ facade under
+ * gaussian-splatting_amd/host/ keeps those class interfaces and calls ONLY the
+ * entry points declared here; each declaration cites the reference code it
+ * replaces (paths relative to the reference checkout).
+ *
+ * Conventions: every function returns GSX_OK (0) or a negative gsx_status; no
+ * exception crosses the ABI; the caller owns every host pointer it passes; the
+ * context owns all device memory; one context per GPU; calls on a context are
+ * serialized on its HIP stream (a context is thread-compatible, not
+ * thread-safe).  Pointers named *_host are host memory, *_dev are device
+ * memory on the context's GPU.  Matrices are column-major float[16] (glm).
+ */
+#ifndef GSX_H
+#define GSX_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct gsx_ctx gsx_ctx;
+
+typedef enum gsx_status {
+    GSX_OK = 0,
+    GSX_E_INVALID = -1,     /* bad argument */
+    GSX_E_HIP = -2,         /* HIP runtime error (see gsx_last_error) */
+    GSX_E_NOMEM = -3,       /* device allocation failed */
+    GSX_E_STATE = -4,       /* call out of order (e.g. sort before upload) */
+    GSX_E_UNSUPPORTED = -5, /* input outside the supported domain */
+    GSX_E_INTERNAL = -6     /* device-side invariant violated (bounded spin expired, overflow) */
+} gsx_status;
+
+/* main.cpp:48-58 / shader_quads_ordered.wgsl:1-10 — the 224-byte uniform block. */
+typedef struct gsx_uniforms {
+    float projectionMatrix[16];
+    float viewMatrix[16];
+    float modelMatrix[16];
+    float splatSize;
+    float cutOff;
+    float fov;
+    uint32_t bayerSize;
+    float bayerScale;
+    float padding[3];
+} gsx_uniforms;
+
+/* Octree (Octree.hpp:57-173) flattened in the BFS order Octree::generate walks
+ * (Octree.cpp:149-187): node i owns splat i.  center3/half3 = bb.center(),
+ * bb.size()/2 (BB.hpp:25-33); parent[0] = UINT32_MAX. */
+typedef struct gsx_octree_flat {
+    uint32_t n_nodes;
+    const float* center3;     /* n_nodes x 3 */
+    const float* half3;       /* n_nodes x 3 */
+    const uint32_t* parent;   /* n_nodes */
+    const uint8_t* is_leaf;   /* n_nodes, Node::is_leaf() (Octree.hpp:67-69) */
+} gsx_octree_flat;
+
+/* HC forest (HC.hpp:28-46) flattened by node->index (== position in HC::splats,
+ * or in GridHC::splats with the per-cell offset of GridHC.cpp:79-88 applied).
+ * parent = UINT32_MAX for the roots left in HC::nodes. weight = Splat::weight()
+ * (Splat.h:24-28), error = Node::error. */
+typedef struct gsx_hc_flat {
+    uint32_t n_nodes;
+    const uint32_t* parent;
+    const uint8_t* is_leaf;
+    const float* error;
+    const float* weight;
+} gsx_hc_flat;
+
+/* Device-side timings of the last frame, milliseconds (HIP events on the
+ * context's stream; valid after gsx_sync). */
+typedef struct gsx_timings {
+    float select_ms;   /* LOD cut kernels */
+    float keygen_ms;   /* depth keys + digit histograms */
+    float sort_ms;     /* radix passes only */
+    float project_ms;
+    float bin_ms;
+    float raster_ms;
+    float total_ms;    /* first to last recorded event of the frame */
+    uint32_t sort_passes;   /* radix passes actually executed (constant-digit passes are skipped) */
+    uint32_t sort_launches; /* kernel launches inside sort_ms */
+    uint64_t tile_pairs;    /* (tile, splat) pairs produced by the binner */
+} gsx_timings;
+
+/* ---- lifecycle (replaces Renderer::init device bring-up, renderer.cpp:3-100) ---- */
+int gsx_create(int device, gsx_ctx** out);
+int gsx_destroy(gsx_ctx* ctx);
+const char* gsx_last_error(const gsx_ctx* ctx);
+int gsx_sync(gsx_ctx* ctx);
+/* 1 = record HIP events around every stage (gsx_get_timings). Default 0. */
+int gsx_set_profiling(gsx_ctx* ctx, int enabled);
+int gsx_get_timings(gsx_ctx* ctx, gsx_timings* out);
+
+/* ---- scene upload: SplatMesh::initializeSplatBuffer (SplatMesh.h:139-147).
+ * aos80 = n reference `Splat` records (Splat.h:19-29: mat4 transform, vec4
+ * color).  Repacked once into SoA float4 arrays in HBM.  The 3x3 covariance
+ * block must be symmetric (it is for split_to_splat/merge outputs), else
+ * GSX_E_UNSUPPORTED. ---- */
+int gsx_upload_splats(gsx_ctx* ctx, const void* aos80_host, uint64_t n);
+int gsx_upload_splats_dev(gsx_ctx* ctx, const void* aos80_dev, uint64_t n);
+
+/* ---- LOD selection (the `indices` a SplatMesh* subclass sorts) ---- */
+/* Base class: indices = iota (SplatMesh.h:68-69). */
+int gsx_select_all(gsx_ctx* ctx);
+/* Explicit list, e.g. HC::get_indices_depth / GridHC::get_indices_error results
+ * (HC.cpp:134-168, GridHC.cpp:76-92), which are view independent and cached by
+ * the host facade.  The list is re-ordered ascending on device so that ties in
+ * the sort break by index. */
+int gsx_select_list(gsx_ctx* ctx, const uint32_t* idx_host, uint32_t m);
+int gsx_set_lod_octree(gsx_ctx* ctx, const gsx_octree_flat* tree);
+int gsx_set_lod_hc(gsx_ctx* ctx, const gsx_hc_flat* forest);
+/* Octree::get_indices(camera, min_screen_area) (Octree.cpp:189-216) with
+ * viewproj = proj * view (BB.hpp:60-61). m_out may be NULL (no host sync). */
+int gsx_select_octree(gsx_ctx* ctx, const float viewproj[16], float min_screen_area, uint32_t* m_out);
+/* HC::get_indices / GridHC::get_indices(camera, threshold, w) (HC.cpp:100-132,
+ * GridHC.cpp:94-111). */
+int gsx_select_hc(gsx_ctx* ctx, const float cam_pos[3], float threshold, uint32_t* m_out);
+/* Copies the current selection (ascending ids) to the host. */
+int gsx_get_selection(gsx_ctx* ctx, uint32_t* idx_out_host, uint32_t capacity, uint32_t* m_out);
+
+/* ---- SplatMesh::sortSplats(indices, cameraPos) (SplatMesh.h:84-114): keys =
+ * glm::distance(position, cameraPos), order = distance descending, ties by
+ * ascending index.  Sorts the current selection; the permutation stays in HBM
+ * (replaces the queue.writeBuffer(sortIndexBuffer) upload, SplatMesh.h:56-57).
+ * idx_out_host (nullable) receives the m sorted indices. ---- */
+int gsx_sort(gsx_ctx* ctx, const float cam_pos[3], uint32_t* idx_out_host);
+int gsx_get_sorted_dev(gsx_ctx* ctx, const uint32_t** idx_dev, uint32_t* m);
+/* Parity aid: the f32 distance key (SplatMesh.h:93) of every selected splat, in
+ * selection order, computed by the same device function the sort uses. */
+int gsx_get_keys(gsx_ctx* ctx, const float cam_pos[3], float* dist_out_host, uint32_t capacity);
+
+/* ---- drawIndexed(6, m) through vs_main/fs_main with the pipeline's blend state
+ * (SplatMesh.h:58; shader_quads_ordered.wgsl:42-73,120-212; main.cpp:338-344;
+ * clear colour renderer.cpp:162-164).  Renders rows [y0,y1) of a width x height
+ * RGBA8 frame from the last gsx_sort result.  rgba8_out_host (nullable)
+ * receives width*height*4 bytes (rows outside the band untouched). ---- */
+int gsx_render(gsx_ctx* ctx, const gsx_uniforms* u, uint32_t width, uint32_t height,
+               uint32_t y0, uint32_t y1, void* rgba8_out_host);
+int gsx_get_framebuffer_dev(gsx_ctx* ctx, const void** rgba8_dev, uint32_t* width, uint32_t* height);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GSX_H */

@@ -1,0 +1,213 @@
+"""GPU parity: upload, depth keys, the onesweep sort and the LOD cuts, called through
+the C ABI (libgsx.so) and compared bit for bit with the CPU oracle / golden fixtures."""
+import numpy as np
+import pytest
+
+from conftest import bits, golden
+
+pytestmark = pytest.mark.gpu
+
+CAMS = [np.array(c, np.float32) for c in ([0.0, 0.0, 5.0], [1.7, -0.4, 4.2], [-6.0, 2.0, 0.5])]
+
+
+def check_contract(perm, keys_by_id, m_ids):
+    """perm is a permutation of m_ids ordered by key descending, index ascending."""
+    assert np.array_equal(np.sort(perm), np.sort(m_ids))
+    k = keys_by_id[perm]
+    assert np.all(k[:-1] >= k[1:])
+    same = k[1:] == k[:-1]
+    assert np.all(perm[1:][same] > perm[:-1][same])
+
+
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 4095, 4096, 4097, 8192, 50000, 262144 + 17])
+def test_sort_matches_oracle(gsx, oracle, synth, n):
+    splats = oracle.raw_to_splat(synth.uniform_cloud(n, seed=n % 97 + 1))
+    gsx.upload(splats)
+    for cam in CAMS[:2]:
+        keys = gsx.keys(cam)
+        assert np.array_equal(bits(keys), bits(oracle.distance_keys(splats, cam)))   # float keys identical on CPU and GPU
+        perm = gsx.sort(cam)
+        assert np.array_equal(perm, oracle.sort_contract(splats, cam))               # bit-exact permutation
+
+
+def test_sort_empty_scene(gsx, oracle):
+    gsx.upload(np.zeros((0, 20), np.float32))
+    assert len(gsx.sort(CAMS[0])) == 0
+
+
+@pytest.mark.parametrize("name", ["uniform1k", "lattice12", "clustered20k"])
+def test_sort_golden(gsx, oracle, synth, name):
+    g = golden("sort.npz")
+    raw = g[f"{name}_raw"] if f"{name}_raw" in g.files else synth.clustered_cloud(20000, seed=6)
+    splats = oracle.raw_to_splat(raw)
+    gsx.upload(splats)
+    for p in range(3):
+        cam = g[f"{name}_p{p}_cam"]
+        ref_keys, ref_perm = g[f"{name}_p{p}_keys"], g[f"{name}_p{p}_perm"]
+        assert np.array_equal(bits(gsx.keys(cam)), bits(ref_keys))
+        perm = gsx.sort(cam)
+        # vs the reference's (unstable) std::sort: same key sequence, same index set per equal-key run
+        assert np.array_equal(bits(ref_keys[perm]), bits(ref_keys[ref_perm]))
+        check_contract(perm, ref_keys, np.arange(len(ref_keys), dtype=np.uint32))
+        assert np.array_equal(perm, oracle.sort_contract(splats, cam))
+
+
+def test_sort_ties_all_equal_and_skipped_passes(gsx, oracle):
+    # every splat at the same distance: all four digits constant -> passes 1..3 skipped, order = ascending index
+    n = 10000
+    splats = np.zeros((n, 20), np.float32)
+    ang = np.linspace(0, 2 * np.pi, n, endpoint=False)
+    splats[:, 12] = np.float32(2.0) * np.cos(ang).astype(np.float32)
+    splats[:, 13] = np.float32(2.0) * np.sin(ang).astype(np.float32)
+    splats[:, 15] = 1.0
+    splats[:, 0] = splats[:, 5] = splats[:, 10] = 0.01
+    gsx.upload(splats)
+    cam = np.zeros(3, np.float32)
+    perm = gsx.sort(cam)
+    assert np.array_equal(perm, oracle.sort_contract(splats, cam))
+    splats[:, 12:15] = [1.0, 2.0, 2.0]     # exactly equal distance 3.0 from the origin
+    gsx.upload(splats)
+    perm = gsx.sort(cam)
+    assert np.array_equal(perm, np.arange(n, dtype=np.uint32))
+    assert gsx.timings()["sort_passes"] == 1
+
+
+def test_sort_wide_key_range(gsx, oracle):
+    # distances spanning many exponents (all four radix digits vary), zeros and huge values
+    rng = np.random.Generator(np.random.PCG64(5))
+    n = 70000
+    splats = np.zeros((n, 20), np.float32)
+    mag = np.exp(rng.uniform(np.log(1e-18), np.log(1e18), size=n))
+    d = rng.standard_normal((n, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    splats[:, 12:15] = (d * mag[:, None]).astype(np.float32)
+    splats[:50, 12:15] = 0.0               # distance exactly 0 from a camera at the origin
+    splats[:, 15] = 1.0
+    gsx.upload(splats)
+    cam = np.zeros(3, np.float32)
+    assert np.array_equal(bits(gsx.keys(cam)), bits(oracle.distance_keys(splats, cam)))
+    assert np.array_equal(gsx.sort(cam), oracle.sort_contract(splats, cam))
+    assert gsx.timings()["sort_passes"] == 4
+
+
+def test_sort_is_repeatable_and_view_dependent(gsx, oracle, synth):
+    splats = oracle.raw_to_splat(synth.clustered_cloud(30000, seed=8))
+    gsx.upload(splats)
+    a = gsx.sort(CAMS[1])
+    b = gsx.sort(CAMS[2])
+    c = gsx.sort(CAMS[1])
+    assert np.array_equal(a, c) and not np.array_equal(a, b)
+
+
+def test_select_list_sorts_sublist(gsx, oracle, synth):
+    splats = oracle.raw_to_splat(synth.uniform_cloud(20000, seed=12))
+    gsx.upload(splats)
+    rng = np.random.Generator(np.random.PCG64(1))
+    sub = rng.permutation(20000)[:7777].astype(np.uint32)     # arbitrary (queue) order, like HC cuts
+    gsx.select_list(sub)
+    assert np.array_equal(gsx.selection(), np.sort(sub))
+    for cam in CAMS:
+        perm = gsx.sort(cam)
+        assert np.array_equal(perm, oracle.sort_contract(splats, cam, np.sort(sub)))
+    gsx.select_list(np.zeros(0, np.uint32))
+    assert len(gsx.sort(CAMS[0])) == 0
+    gsx.select_all()
+    assert np.array_equal(gsx.sort(CAMS[0]), oracle.sort_contract(splats, CAMS[0]))
+
+
+def _octree_parent(first_child, n_children):
+    n = len(n_children)
+    parent = np.full(n, 0xFFFFFFFF, np.uint32)
+    for i in range(n):
+        parent[first_child[i]:first_child[i] + n_children[i]] = i
+    return parent
+
+
+def test_octree_select_golden(gsx, oracle):
+    g = golden("lod.npz")
+    fc, nc = g["oc_first_child"], g["oc_n_children"]
+    gsx.upload(g["oc_splats"])
+    gsx.set_lod_octree(g["oc_center3"], g["oc_half3"], _octree_parent(fc, nc), (nc == 0).astype(np.uint8))
+    for p in range(3):
+        vp = g["pose_viewproj"][p]
+        cam = g["pose_world"][p][12:15]
+        for t, thr in enumerate(g["oc_thr"]):
+            ref_cut = g[f"oc_cut_p{p}_t{t}"]
+            m = gsx.select_octree(vp, float(thr))
+            assert m == len(ref_cut)
+            assert np.array_equal(gsx.selection(), ref_cut)          # Octree.cpp:189-216 (BFS order is ascending)
+            perm = gsx.sort(cam)
+            assert np.array_equal(perm, oracle.sort_contract(g["oc_splats"], cam, ref_cut))
+
+
+def _hc_parent(child2, n):
+    parent = np.full(n, 0xFFFFFFFF, np.uint32)
+    c = child2.reshape(-1, 2)
+    for i in range(n):
+        if c[i, 0] != 0xFFFFFFFF:
+            parent[c[i, 0]] = i
+            parent[c[i, 1]] = i
+    return parent
+
+
+@pytest.mark.parametrize("prefix,thr_key", [("hc", "hc_mthr"), ("g", "g_mthr")])
+def test_hc_metric_select_golden(gsx, oracle, prefix, thr_key):
+    g = golden("lod.npz")
+    splats, child2 = g[f"{prefix}_splats"], g[f"{prefix}_child2"]
+    n = len(splats)
+    leaf = (child2.reshape(-1, 2)[:, 0] == 0xFFFFFFFF).astype(np.uint8)
+    gsx.upload(splats)
+    gsx.set_lod_hc(_hc_parent(child2, n), leaf, g[f"{prefix}_error"], g[f"{prefix}_weight"])
+    for p in range(3):
+        cam = g["pose_world"][p][12:15]
+        for t, thr in enumerate(g[thr_key]):
+            ref_cut = g[f"{prefix}_cut_metric_p{p}_t{t}"]
+            m = gsx.select_hc(cam, float(thr))
+            assert m == len(ref_cut)
+            assert np.array_equal(gsx.selection(), np.sort(ref_cut))  # same index set (reference: queue order)
+            assert np.array_equal(gsx.sort(cam), oracle.sort_contract(splats, cam, np.sort(ref_cut)))
+
+
+def test_gridhc_depth_cut_through_select_list(gsx, oracle):
+    g = golden("lod.npz")
+    gsx.upload(g["g_splats"])
+    cam = g["pose_world"][1][12:15]
+    for d in g["g_depths"]:
+        ref_cut = g[f"g_cut_depth_{d}"]
+        gsx.select_list(ref_cut)
+        assert np.array_equal(gsx.sort(cam), oracle.sort_contract(g["g_splats"], cam, np.sort(ref_cut)))
+
+
+def test_upload_rejects_asymmetric_covariance(gsx, pkg):
+    s = np.zeros((4, 20), np.float32)
+    s[:, 0] = s[:, 5] = s[:, 10] = 0.01
+    s[:, 15] = 1.0
+    s[2, 1] = 0.5           # transform[0][1] != transform[1][0]
+    with pytest.raises(pkg.GsxError) as e:
+        gsx.upload(s)
+    assert e.value.code == pkg.GSX_E_UNSUPPORTED
+
+
+def test_large_sort_properties(gsx, oracle, synth):
+    """cfg-2 size (6M): size-independent properties instead of a full oracle sort."""
+    n = 6_000_000
+    raw = synth.clustered_cloud(n, seed=6)
+    splats = oracle.raw_to_splat(raw)
+    gsx.upload(splats)
+    cam = np.array([0.0, 0.0, 5.0], np.float32)
+    perm = gsx.sort(cam)
+    keys = oracle.distance_keys(splats, cam)
+    k = keys[perm]
+    assert np.all(k[:-1] >= k[1:])                                   # sortedness
+    seen = np.zeros(n, bool)
+    seen[perm] = True
+    assert seen.all() and len(perm) == n                             # a permutation
+    same = k[1:] == k[:-1]
+    assert np.all(perm[1:][same] > perm[:-1][same])                  # ties by ascending index
+    # idempotence: sorting the already-sorted selection order gives the same permutation
+    assert np.array_equal(gsx.sort(cam), perm)
+    # spot check a window against the oracle's full order
+    sub = np.sort(perm[1000:21000])
+    gsx.select_list(sub)
+    assert np.array_equal(gsx.sort(cam), oracle.sort_contract(splats, cam, sub))
+    gsx.select_all()
