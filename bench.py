@@ -1,0 +1,216 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the gsx hot path on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: launched by torch.distributed.run, one rank per GPU, RCCL)
+
+Workload (BASELINE.json configs[1]): 6M-splat synthetic clustered scene, one
+1920x1080 view per step.  A *step* is one complete frame of the hot path on
+data already resident in HBM: depth keys -> onesweep sort -> projection ->
+tile binning -> tile raster into a device RGBA8 framebuffer (no readback).
+At N > 1 the path shards by camera view over a replicated splat set (weak
+scaling: every rank renders its own view each step) and the finished frames are
+gathered to rank 0 with RCCL inside the timed region.
+
+Prints ONE JSON line on rank 0.  `value` = splats sorted (and drawn) per second
+over whole frames, aggregated over ranks; `fps_1080p` and the sort-only rate are
+reported next to it.  `roofline` describes the radix-pass kernel (k_sort_pass);
+`cpu_baseline` times the CPU port of the reference's sortSplats on rank 0.
+"""
+import argparse
+import importlib
+import importlib.util
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+SORT_PASS_BYTES_PER_SPLAT = 16  # one radix pass: read key+index (8 B), write key+index (8 B)
+SORT_TOTAL_BYTES_PER_SPLAT = 16 + 4 + 4 * 16  # keygen 16 B read + 4 B key write, 4 passes (pass 0 regenerates the index: 12 B)
+
+
+def load_pkg():
+    name = "gaussian_splatting_amd"
+    if name in sys.modules:
+        return sys.modules[name]
+    pkg_dir = os.path.join(ROOT, "gaussian-splatting_amd")
+    spec = importlib.util.spec_from_file_location(name, os.path.join(pkg_dir, "__init__.py"),
+                                                  submodule_search_locations=[pkg_dir])
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def orbit_views(pkg, n_views, width, height):
+    """8 azimuths x 8 elevations style pose set at distance 5 (SURVEY 8d cfg 4), any count."""
+    cam = importlib.import_module("gaussian_splatting_amd.camera")
+    views = []
+    for v in range(n_views):
+        az = 2.0 * np.pi * (v % 8) / 8.0 + 0.05 * (v // 64)
+        el = np.deg2rad(-35.0 + 10.0 * ((v // 8) % 8))
+        world = cam.orbit_world(5.0, az, el)
+        view, proj, pos = cam.camera_matrices(world, 45.0, width / height)
+        views.append((view, proj, pos))
+    return views
+
+
+class DevArray:
+    """Zero-copy torch view of a raw device pointer (framebuffer) via __cuda_array_interface__."""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"data": (ptr, False), "shape": (nbytes,), "typestr": "|u1", "version": 2}
+
+
+def cpu_baseline(splats, views, n_frames):
+    """CPU port of SplatMesh::sortSplats (oracle, test infrastructure) on this host, 1 core."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import orc
+    O = orc.Oracle()
+    idx = np.arange(splats.shape[0], dtype=np.uint32)   # persistent across frames, like SplatMesh::indices
+    secs = 0.0
+    for f in range(n_frames):
+        secs += O.sort_reference_port(splats, views[f % len(views)][2], idx)
+    return splats.shape[0] * n_frames / secs, secs
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--splats", type=int, default=6_000_000)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--scene", default="clustered")
+    ap.add_argument("--cpu-frames", type=int, default=5, help="frames of the CPU baseline (0 = skip)")
+    ap.add_argument("--no-gather", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback)"
+
+    pkg = load_pkg()
+    synth = importlib.import_module("gaussian_splatting_amd.synth")
+    scene = importlib.import_module("gaussian_splatting_amd.scene")
+    raw = synth.SCENES[a.scene](a.splats)
+    splats = scene.raw_to_splats(pkg, raw, center=False)      # host half of ResourceManager (libgsx, C++)
+    W, H = a.width, a.height
+    views = orbit_views(pkg, 64, W, H)
+    # view-batch sharding: rank r owns views r, r+world, ... (independent units, no data-path collective)
+    my_views = views[rank::world] if world > 1 else views[:1]
+
+    g = pkg.Gsx(local_rank)
+    g.upload(splats)
+    g.set_profiling(True)
+    uniforms = [pkg.make_uniforms(v[1], v[0]) for v in my_views]
+
+    fb_bytes = W * H * 4
+    gather_buf = None
+
+    def step(i):
+        v = i % len(my_views)
+        g.sort(my_views[v][2], download=False)
+        g.render(uniforms[v], W, H, download=False)
+
+    def gather():
+        """Framebuffer gather to rank 0 over RCCL (direct sends, one xGMI link per peer)."""
+        nonlocal gather_buf
+        g.sync()
+        ptr, _, _ = g.framebuffer_dev()
+        fb = torch.as_tensor(DevArray(ptr, fb_bytes), device=torch.device("cuda", local_rank))
+        if rank == 0:
+            if gather_buf is None:
+                gather_buf = [torch.empty(fb_bytes, dtype=torch.uint8, device=fb.device) for _ in range(world)]
+            dist.gather(fb, gather_buf, dst=0)
+        else:
+            dist.gather(fb, None, dst=0)
+
+    def fence():
+        if dist is not None:
+            dist.barrier()
+        g.sync()
+        torch.cuda.synchronize()
+
+    for i in range(a.warmup):
+        step(i)
+        if dist is not None and not a.no_gather:
+            gather()
+    fence()
+    acc = {}
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        step(i)
+        if dist is not None and not a.no_gather:
+            gather()
+        t = g.timings()        # HIP-event stage times of this frame (synchronises the frame, like a present)
+        for k, val in t.items():
+            acc[k] = acc.get(k, 0.0) + val
+    fence()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=torch.device("cuda", local_rank))
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    if rank == 0:
+        K = a.steps
+        n = a.splats
+        passes = acc["sort_passes"] / K
+        sort_ms = acc["sort_ms"] / K
+        pass_ms = sort_ms / max(passes, 1.0)
+        achieved = SORT_PASS_BYTES_PER_SPLAT * n / (pass_ms * 1e-3) / 1e9
+        keysort_ms = (acc["keygen_ms"] + acc["sort_ms"]) / K
+        out = {
+            "metric": "splats_sorted_per_s (whole 1080p frame: keys+sort+project+bin+raster)",
+            "value": n * K * world / elapsed,
+            "unit": "splats/s",
+            "n_gpus": world,
+            "steps": K,
+            "warmup": a.warmup,
+            "ms_per_step": elapsed / K * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32 keys / u32 radix",
+            "data": "synthetic",
+            "config": {"workload": f"cfg2: {n}-splat clustered synthetic scene, single view {W}x{H} per step",
+                       "splats": n, "width": W, "height": H, "views_per_step_per_gpu": 1,
+                       "sharding": "camera views over replicated splats" + ("" if a.no_gather or world == 1 else " + RCCL framebuffer gather to rank 0")},
+            "fps_1080p": K * world / elapsed,
+            "sort_only_splats_per_s": n / (keysort_ms * 1e-3),
+            "sort_only_hbm_frac": SORT_TOTAL_BYTES_PER_SPLAT * n / (keysort_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "stage_ms": {k: acc[k] / K for k in ("select_ms", "keygen_ms", "sort_ms", "project_ms", "bin_ms", "raster_ms", "total_ms")},
+            "tile_pairs": int(acc["tile_pairs"] / K),
+            "roofline": {"kernel": "k_sort_pass (one 8-bit onesweep pass)", "bound": "hbm", "achieved": achieved,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "avg_launch_ms": pass_ms, "launches_per_step": passes,
+                         "algorithmic_bytes_per_launch": SORT_PASS_BYTES_PER_SPLAT * n},
+        }
+        if a.cpu_frames > 0:
+            v, secs = cpu_baseline(splats, views, a.cpu_frames)
+            out["cpu_baseline"] = {"value": v, "unit": "splats/s", "cores": 1, "kind": "port",
+                                   "sample": f"{a.cpu_frames} consecutive frames of the full {n}-splat sortSplats "
+                                             f"(distances alloc + key loop + std::sort, {secs:.1f} s of CPU; sort only, the "
+                                             "reference has no CPU raster)"}
+        print(json.dumps(out), flush=True)
+    g.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -144,6 +144,25 @@ int gsx_render(gsx_ctx* ctx, const gsx_uniforms* u, uint32_t width, uint32_t hei
                uint32_t y0, uint32_t y1, void* rgba8_out_host);
 int gsx_get_framebuffer_dev(gsx_ctx* ctx, const void** rgba8_dev, uint32_t* width, uint32_t* height);
 
+/* ---- host-only helpers (no GPU touched): the load-time half of ResourceManager and
+ * the scene-graph math that produces the path's inputs. ---- */
+/* raw_to_split + optional mean-centering + split_to_splat over n 32-byte SplatRaw
+ * records (Splat.h:60-91, ResourceManager.cpp:52-62) -> n 80-byte Splat records. */
+int gsx_host_convert_raw(const void* raw32_host, uint64_t n, int center, void* aos80_out_host);
+/* ResourceManager::loadSplatsRaw(path, center) (ResourceManager.cpp:36-65) + split_to_splat.
+ * A file that cannot be opened yields n = 0 and GSX_OK, as the reference returns an
+ * empty vector.  *aos80_out is malloc'ed; release with gsx_host_free. */
+int gsx_host_load_splat_file(const char* path, int center, void** aos80_out, uint64_t* n_out);
+void gsx_host_free(void* p);
+/* Camera::getViewMatrix / getProjectionMatrix (Camera.h:27-34) and proj*view (BB.hpp:60-61).
+ * Any output pointer may be NULL. */
+int gsx_host_camera(const float world16[16], float fov_deg, float aspect, float znear, float zfar,
+                    float view16[16], float proj16[16], float viewproj16[16]);
+/* World matrix of OrbitCamera(distance)'s camera after n_rot successive
+ * Node::rotate(axis_i, angle_i) calls on the orbit node (OrbitCamera.h:24-30,
+ * Node.cpp:10-27, main.cpp:469-486). */
+int gsx_host_orbit_pose(float distance, const float* axes3, const float* angles, uint32_t n_rot, float world16[16]);
+
 #ifdef __cplusplus
 }
 #endif
