@@ -14,7 +14,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgsx.so")
+LIB_PATH = os.environ.get("GSX_LIB") or os.path.join(_HERE, "libgsx.so")
 
 GSX_OK, GSX_E_INVALID, GSX_E_HIP, GSX_E_NOMEM, GSX_E_STATE, GSX_E_UNSUPPORTED, GSX_E_INTERNAL = 0, -1, -2, -3, -4, -5, -6
 

@@ -5,7 +5,8 @@
 
 #include "gsx_internal.h"
 
-uint64_t gsx_sort_workspace_bytes(uint64_t cap);
+uint64_t gsx_sort_workspace_words(uint64_t cap);
+int gsx_launch_aabb(gsx_ctx* c);
 
 namespace {
 
@@ -33,7 +34,8 @@ int check_flags(gsx_ctx* c) {
     GSX_HIP(c, hipStreamSynchronize(c->stream));
     if (c->flags_host->spin_expired) { c->err = "device: bounded look-back spin expired (results invalid)"; return GSX_E_INTERNAL; }
     if (c->flags_host->pair_overflow) { c->err = "device: tile pair buffer overflow"; return GSX_E_INTERNAL; }
-    if (c->flags_host->pad) { c->err = "selection list holds an id >= n"; return GSX_E_INVALID; }
+    if (c->flags_host->bad_index) { c->err = "selection list holds an id >= n"; return GSX_E_INVALID; }
+    if (c->flags_host->key_bound) { c->err = "device: a depth key left the scene's distance bound (non-finite position?)"; return GSX_E_INTERNAL; }
     return GSX_OK;
 }
 
@@ -47,12 +49,8 @@ int alloc_scene(gsx_ctx* c, uint64_t n) {
     for (int b = 0; b < 2; ++b)
         if ((rc = dev_alloc(c, &c->keys[b], n)) || (rc = dev_alloc(c, &c->vals[b], n))) return rc;
     c->sort_cap = n;
-    c->sort_zero_bytes = gsx_sort_workspace_bytes(n);
-    {
-        uint8_t* z = reinterpret_cast<uint8_t*>(c->sort_zero);
-        if ((rc = dev_alloc(c, &z, c->sort_zero_bytes))) return rc;
-        c->sort_zero = reinterpret_cast<GsxSortZero*>(z);
-    }
+    c->sort_ws_words = gsx_sort_workspace_words(n);
+    if ((rc = dev_alloc(c, &c->sort_ws, c->sort_ws_words))) return rc;
     if ((rc = dev_alloc(c, &c->proj, n))) return rc;
     c->proj_cap = n;
     // LOD / list-selection scratch (flags padded for 16-byte vector loads)
@@ -88,15 +86,14 @@ int gsx_create(int device, gsx_ctx** out) {
         if (hipEventCreate(&c->ev[i]) != hipSuccess) return fail(GSX_E_HIP);
     if (hipMalloc(reinterpret_cast<void**>(&c->m_dev), 16) != hipSuccess) return fail(GSX_E_NOMEM);
     if (hipMalloc(reinterpret_cast<void**>(&c->pair_total_dev), 16) != hipSuccess) return fail(GSX_E_NOMEM);
-    if (hipMalloc(reinterpret_cast<void**>(&c->plan), sizeof(GsxSortPlan)) != hipSuccess) return fail(GSX_E_NOMEM);
+    if (hipMalloc(reinterpret_cast<void**>(&c->aabb_dev), 32) != hipSuccess) return fail(GSX_E_NOMEM);
     if (hipMalloc(reinterpret_cast<void**>(&c->flags), sizeof(GsxDevFlags)) != hipSuccess) return fail(GSX_E_NOMEM);
-    if (hipHostMalloc(reinterpret_cast<void**>(&c->plan_host), sizeof(GsxSortPlan), hipHostMallocDefault) != hipSuccess)
+    if (hipHostMalloc(reinterpret_cast<void**>(&c->host_word), 64, hipHostMallocDefault) != hipSuccess)
         return fail(GSX_E_NOMEM);
     if (hipHostMalloc(reinterpret_cast<void**>(&c->flags_host), sizeof(GsxDevFlags), hipHostMallocDefault) != hipSuccess)
         return fail(GSX_E_NOMEM);
     if (hipMemset(c->flags, 0, sizeof(GsxDevFlags)) != hipSuccess) return fail(GSX_E_HIP);
     if (hipMemset(c->m_dev, 0, 16) != hipSuccess) return fail(GSX_E_HIP);
-    if (hipMemset(c->plan, 0, sizeof(GsxSortPlan)) != hipSuccess) return fail(GSX_E_HIP);
     *out = c;
     return GSX_OK;
 }
@@ -110,11 +107,10 @@ int gsx_destroy(gsx_ctx* c) {
     dev_free(&c->lod_a); dev_free(&c->lod_b); dev_free(&c->lod_parent); dev_free(&c->lod_leaf);
     dev_free(&c->lod_stop); dev_free(&c->lod_emit); dev_free(&c->lod_block_sums);
     for (int b = 0; b < 2; ++b) { dev_free(&c->keys[b]); dev_free(&c->vals[b]); dev_free(&c->pair_key[b]); dev_free(&c->pair_val[b]); }
-    dev_free(&c->sort_zero); dev_free(&c->plan); dev_free(&c->flags);
+    dev_free(&c->sort_ws); dev_free(&c->aabb_dev); dev_free(&c->flags); dev_free(&c->pair_ws);
     dev_free(&c->proj); dev_free(&c->splat_ntiles); dev_free(&c->scan_block_sums);
     dev_free(&c->tile_start); dev_free(&c->pair_total_dev); dev_free(&c->fb);
-    if (c->bin_zero) { (void)hipFree(c->bin_zero); c->bin_zero = nullptr; }
-    if (c->plan_host) (void)hipHostFree(c->plan_host);
+    if (c->host_word) (void)hipHostFree(c->host_word);
     if (c->flags_host) (void)hipHostFree(c->flags_host);
     for (int i = 0; i < EV_COUNT; ++i)
         if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
@@ -158,9 +154,8 @@ int gsx_get_timings(gsx_ctx* c, gsx_timings* out) {
         t.total_ms = t.select_ms + t.keygen_ms + t.sort_ms + t.project_ms + t.bin_ms + t.raster_ms;
     }
     if (c->sorted_valid) {
-        GSX_HIP(c, hipMemcpy(c->plan_host, c->plan, 64, hipMemcpyDeviceToHost));
-        t.sort_passes = c->plan_host->passes_run;
-        t.sort_launches = GSX_PASSES;
+        t.sort_passes = c->sort_passes;
+        t.sort_launches = 3 * c->sort_passes - 1;   // pass 0's count is fused into the key kernel
     }
     *out = t;
     return GSX_OK;
@@ -172,6 +167,7 @@ static int upload_common(gsx_ctx* c, const void* aos_dev, uint64_t n) {
     c->n = n;
     GSX_HIP(c, hipMemsetAsync(c->flags, 0, sizeof(GsxDevFlags), c->stream));
     if ((rc = gsx_launch_upload(c, aos_dev, n))) return rc;
+    if ((rc = gsx_launch_aabb(c))) return rc;
     c->lod_kind = 0;
     c->sorted_valid = false;
     if ((rc = gsx_select_all(c))) return rc;
@@ -285,9 +281,9 @@ static int finish_select(gsx_ctx* c, uint32_t* m_out) {
     c->sorted_valid = false;
     c->ev_recorded[EV_SEL1] = c->profiling;
     if (m_out) {
-        GSX_HIP(c, hipMemcpyAsync(&c->plan_host->pad, c->m_dev, 4, hipMemcpyDeviceToHost, c->stream));
+        GSX_HIP(c, hipMemcpyAsync(c->host_word, c->m_dev, 4, hipMemcpyDeviceToHost, c->stream));
         GSX_HIP(c, hipStreamSynchronize(c->stream));
-        *m_out = c->plan_host->pad;
+        *m_out = *c->host_word;
     }
     return GSX_OK;
 }
@@ -314,9 +310,9 @@ int gsx_get_selection(gsx_ctx* c, uint32_t* idx_out, uint32_t capacity, uint32_t
     if (!c || !m_out) return GSX_E_INVALID;
     int rc = set_device(c);
     if (rc) return rc;
-    GSX_HIP(c, hipMemcpyAsync(&c->plan_host->pad, c->m_dev, 4, hipMemcpyDeviceToHost, c->stream));
+    GSX_HIP(c, hipMemcpyAsync(c->host_word, c->m_dev, 4, hipMemcpyDeviceToHost, c->stream));
     GSX_HIP(c, hipStreamSynchronize(c->stream));
-    const uint32_t m = c->plan_host->pad;
+    const uint32_t m = *c->host_word;
     *m_out = m;
     if (!idx_out) return GSX_OK;
     if (capacity < m) { c->err = "selection buffer too small"; return GSX_E_INVALID; }
@@ -336,10 +332,10 @@ int gsx_sort(gsx_ctx* c, const float cam_pos[3], uint32_t* idx_out_host) {
     if ((rc = gsx_launch_sort(c))) return rc;
     c->ev_recorded[EV_SORT1] = c->profiling;
     if (idx_out_host) {
-        GSX_HIP(c, hipMemcpyAsync(c->plan_host, c->plan, 64, hipMemcpyDeviceToHost, c->stream));
+        GSX_HIP(c, hipMemcpyAsync(c->host_word, c->m_dev, 4, hipMemcpyDeviceToHost, c->stream));
         if ((rc = check_flags(c))) return rc;
-        const uint32_t m = c->plan_host->m;
-        if (m) GSX_HIP(c, hipMemcpy(idx_out_host, c->vals[c->plan_host->final_buf], static_cast<uint64_t>(m) * 4, hipMemcpyDeviceToHost));
+        const uint32_t m = *c->host_word;
+        if (m) GSX_HIP(c, hipMemcpy(idx_out_host, c->vals[c->sorted_buf], static_cast<uint64_t>(m) * 4, hipMemcpyDeviceToHost));
     }
     return GSX_OK;
 }
@@ -349,10 +345,10 @@ int gsx_get_sorted_dev(gsx_ctx* c, const uint32_t** idx_dev, uint32_t* m) {
     if (!c->sorted_valid) { c->err = "no sorted permutation yet"; return GSX_E_STATE; }
     int rc = set_device(c);
     if (rc) return rc;
-    GSX_HIP(c, hipMemcpyAsync(c->plan_host, c->plan, 64, hipMemcpyDeviceToHost, c->stream));
+    GSX_HIP(c, hipMemcpyAsync(c->host_word, c->m_dev, 4, hipMemcpyDeviceToHost, c->stream));
     if ((rc = check_flags(c))) return rc;
-    *idx_dev = c->vals[c->plan_host->final_buf];
-    *m = c->plan_host->m;
+    *idx_dev = c->vals[c->sorted_buf];
+    *m = *c->host_word;
     return GSX_OK;
 }
 
@@ -365,9 +361,9 @@ int gsx_get_keys(gsx_ctx* c, const float cam_pos[3], float* dist_out_host, uint3
     c->sorted_valid = false;  // keys[0] doubles as scratch here
     float* dev = reinterpret_cast<float*>(c->keys[0]);
     if ((rc = gsx_launch_keys_only(c, dev))) return rc;
-    GSX_HIP(c, hipMemcpyAsync(&c->plan_host->pad, c->m_dev, 4, hipMemcpyDeviceToHost, c->stream));
+    GSX_HIP(c, hipMemcpyAsync(c->host_word, c->m_dev, 4, hipMemcpyDeviceToHost, c->stream));
     GSX_HIP(c, hipStreamSynchronize(c->stream));
-    const uint32_t m = c->plan_host->pad;
+    const uint32_t m = *c->host_word;
     if (m) GSX_HIP(c, hipMemcpy(dist_out_host, dev, static_cast<uint64_t>(m) * 4, hipMemcpyDeviceToHost));
     return GSX_OK;
 }

@@ -9,44 +9,31 @@
 #include "../../include/gsx.h"
 
 #define GSX_WAVE 64
-#define GSX_RADIX 256
-#define GSX_PASSES 4
 
 // ---- sort geometry: one workgroup sorts one tile of NT*IPT keys per pass ----
+#ifndef GSX_SORT_NT
 #define GSX_SORT_NT 256
+#endif
+#ifndef GSX_SORT_IPT
 #define GSX_SORT_IPT 16
+#endif
 #define GSX_SORT_TILE (GSX_SORT_NT * GSX_SORT_IPT)
+#define GSX_PAIR_NT 256
+#define GSX_PAIR_IPT 16
+#define GSX_PAIR_TILE (GSX_PAIR_NT * GSX_PAIR_IPT)
 
 // ---- raster geometry ----
 #define GSX_TILE_W 16
 #define GSX_TILE_H 16
-
-// Device-resident plan of one sort, written by k_sort_plan and read by every
-// radix pass and by the consumers of the sorted permutation.
-struct GsxSortPlan {
-    uint32_t skip[GSX_PASSES];   // pass p copies nothing (all keys share digit p)
-    uint32_t src[GSX_PASSES];    // ping-pong buffer pass p reads (0/1)
-    uint32_t final_buf;          // buffer holding the sorted result
-    uint32_t m;                  // number of keys
-    uint32_t passes_run;
-    uint32_t pad;
-    uint32_t gbase[GSX_PASSES][GSX_RADIX];  // exclusive scan of the global digit histograms
-};
-
-// Small block zeroed by ONE hipMemsetAsync per sort; the look-back status words
-// follow it in the same allocation.
-struct GsxSortZero {
-    uint32_t ghist[GSX_PASSES][GSX_RADIX];
-    uint32_t tile_ctr[GSX_PASSES];
-    uint32_t pad[12];
-};
 
 // Error/diagnostic words written by kernels (never zeroed implicitly).
 struct GsxDevFlags {
     uint32_t spin_expired;   // a bounded look-back spin ran out
     uint32_t asym_cov;       // upload saw a non-symmetric covariance block
     uint32_t pair_overflow;  // binner produced more pairs than the buffer holds
-    uint32_t pad;
+    uint32_t bad_index;      // a selection list named an id >= n
+    uint32_t key_bound;      // a depth key fell outside the host-computed [dmin, dmax] bound (NaN position?)
+    uint32_t pad[3];
 };
 
 // Projected splat record (48 B), written by k_project in ORIGINAL splat order.
@@ -95,12 +82,16 @@ struct gsx_ctx {
     uint32_t* keys[2] = {nullptr, nullptr};
     uint32_t* vals[2] = {nullptr, nullptr};
     uint64_t sort_cap = 0;
-    GsxSortZero* sort_zero = nullptr;  // + status words behind it
-    uint64_t sort_zero_bytes = 0;
-    GsxSortPlan* plan = nullptr;
-    GsxSortPlan* plan_host = nullptr;  // pinned
+    uint32_t* sort_ws = nullptr;       // radix count matrix + digit totals
+    uint64_t sort_ws_words = 0;
+    uint32_t* host_word = nullptr;     // pinned staging word(s) for small device->host reads
     bool sorted_valid = false;
+    uint32_t sorted_buf = 0;           // vals[sorted_buf] holds the permutation
+    uint32_t sort_passes = 0;
     float cam[3] = {0, 0, 0};
+    float aabb_min[3] = {0, 0, 0}, aabb_max[3] = {0, 0, 0};  // of the uploaded positions
+    bool aabb_valid = false;
+    float* aabb_dev = nullptr;         // 6 floats (ordered-int encoded during the reduction)
 
     GsxDevFlags* flags = nullptr;
     GsxDevFlags* flags_host = nullptr; // pinned
@@ -120,8 +111,8 @@ struct gsx_ctx {
     uint8_t* fb = nullptr;             // RGBA8 width*height
     uint64_t fb_cap = 0;
     uint32_t fb_w = 0, fb_h = 0;
-    void* bin_zero = nullptr;          // zero block + status for the pair sort
-    uint64_t bin_zero_bytes = 0;
+    uint32_t* pair_ws = nullptr;       // radix workspace of the pair sort
+    uint64_t pair_ws_words = 0;
 
     // timing
     hipEvent_t ev[16] = {};

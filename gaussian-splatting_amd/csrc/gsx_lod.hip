@@ -16,7 +16,7 @@
 // the reference's.  The reference emits BFS/queue order; the sort's tie rule
 // needs ascending ids, which is what compaction yields.
 #include "gsx_internal.h"
-#include "gsx_onesweep.hpp"
+#include "gsx_radix.hpp"
 
 struct GsxMat4 { float m[16]; };
 
@@ -200,7 +200,7 @@ __global__ __launch_bounds__(256) void k_mark_list(const uint32_t* __restrict__ 
     if (k >= m) return;
     const uint32_t i = list[k];
     if (i < n) emit[i] = 1;
-    else atomicOr(&flags->pad, 1u);  // out-of-range id
+    else atomicOr(&flags->bad_index, 1u);  // out-of-range id
 }
 
 // `list` is a device staging copy of the caller's ids (c->vals[0] is free between sorts).

@@ -1,0 +1,325 @@
+// gsx_radix.hpp — stable LSD radix sort of (key, u32 value) pairs for gfx950,
+// as three kernels per digit pass:
+//
+//   H  k_radix_hist     every block counts the digits of ITS contiguous key range
+//   S  k_radix_scan     one block per digit: exclusive scan of that digit's counts
+//                       over blocks (+ the digit's total)
+//   X  k_radix_scatter  every block re-reads its range tile by tile, ranks the keys
+//                       with wave64 ballots, stages them through LDS in digit order
+//                       and writes them out; per-digit running offsets live in LDS
+//
+// Replaces the reference's std::sort(indices, distances[a] > distances[b])
+// (SplatMesh.h:97-108); the same passes order the binner's (tile, splat) pairs.
+// Stability turns "input in ascending index order" into the contract's tie rule
+// (distance descending, then index ascending).
+//
+// Why not a chained-scan ("onesweep") pass: on MI355X the look-back's status words
+// cross eight non-coherent XCD L2s, so every hop is a fabric round trip; measured
+// on 6M keys the look-back cost 25 us of a 66 us pass, and the whole pass is
+// latency- not bandwidth-bound.  Here no workgroup ever waits on another one: the
+// only cross-workgroup data is the small count matrix handed over at kernel
+// boundaries, a block's outputs for one digit are contiguous across its tiles
+// (long runs for the write combiner), and nothing can spin or hang.
+//
+// Ranking uses no LDS read-modify-write chain: per item 8-9 ballots give the
+// peer mask, the lowest peer issues ONE returning ds_add, and results are
+// broadcast afterwards, so the 12-16 items of a thread are in flight together.
+#pragma once
+#include "gsx_internal.h"
+
+#define GSX_RADIX_MAX_BITS 9
+#define GSX_RADIX_MAX_DIGITS (1 << GSX_RADIX_MAX_BITS)
+#define GSX_RADIX_MAX_BLOCKS 2048
+
+__device__ __forceinline__ uint32_t gsx_lane() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+
+__device__ __forceinline__ uint32_t gsx_mbcnt(uint64_t mask) {
+    return __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(mask >> 32),
+                                     __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(mask), 0u));
+}
+
+// Exclusive scan of one value per thread over a block of NT threads.
+template <int NT>
+__device__ __forceinline__ uint32_t gsx_block_excl_scan(uint32_t v, uint32_t* s_tmp, uint32_t* total) {
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t t = __shfl_up(incl, off);
+        if (lane >= static_cast<uint32_t>(off)) incl += t;
+    }
+    if (lane == 63) s_tmp[wave] = incl;
+    __syncthreads();
+    uint32_t wave_off = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < NT / 64; ++w) {
+        const uint32_t t = s_tmp[w];
+        if (static_cast<uint32_t>(w) < wave) wave_off += t;
+        tot += t;
+    }
+    __syncthreads();
+    if (total) *total = tot;
+    return wave_off + incl - v;
+}
+
+// Lanes of the wave holding the same digit as this lane (all 64 lanes must call).
+__device__ __forceinline__ uint64_t gsx_match_digit(uint32_t d, uint32_t bits) {
+    uint64_t peers = ~0ull;
+#pragma unroll
+    for (int b = 0; b < GSX_RADIX_MAX_BITS; ++b) {
+        if (static_cast<uint32_t>(b) < bits) {   // wave-uniform
+            const bool bit = (d >> b) & 1u;
+            const uint64_t bal = __builtin_amdgcn_ballot_w64(bit);
+            peers &= bit ? bal : ~bal;
+        }
+    }
+    return peers;
+}
+
+// Tiles [first, last) of block `b` when n_tiles tiles are dealt to `g` blocks in contiguous ranges.
+__device__ __forceinline__ void gsx_block_tiles(uint32_t n_tiles, uint32_t g, uint32_t b, uint32_t& first, uint32_t& last) {
+    const uint32_t per = (n_tiles + g - 1) / g;
+    first = min(b * per, n_tiles);
+    last = min(first + per, n_tiles);
+}
+
+// ---- H: digit counts of each block's range -> cnt[d * G + b] -----------------
+// Also usable as a device function by producers that already hold the keys
+// (the depth-key kernel counts pass 0 while it writes the keys).
+template <int NT>
+__device__ __forceinline__ void gsx_hist_flush(uint32_t (*s_whist)[GSX_RADIX_MAX_DIGITS], uint32_t nd, uint32_t* __restrict__ cnt) {
+    __syncthreads();
+    for (uint32_t d = threadIdx.x; d < nd; d += NT) {
+        uint32_t acc = 0;
+#pragma unroll
+        for (int w = 0; w < NT / 64; ++w) acc += s_whist[w][d];
+        cnt[static_cast<uint64_t>(d) * gridDim.x + blockIdx.x] = acc;
+    }
+}
+
+template <typename KeyT, int NT, int IPT>
+__global__ __launch_bounds__(NT) void k_radix_hist(const KeyT* __restrict__ keys, const uint32_t* __restrict__ count_ptr,
+                                                   uint32_t shift, uint32_t bits, uint32_t* __restrict__ cnt) {
+    __shared__ uint32_t s_whist[NT / 64][GSX_RADIX_MAX_DIGITS];
+    constexpr int TILE = NT * IPT;
+    const uint32_t nd = 1u << bits, mask = nd - 1u;
+    const uint32_t count = *count_ptr;
+    for (uint32_t t = threadIdx.x; t < (NT / 64) * GSX_RADIX_MAX_DIGITS; t += NT) (&s_whist[0][0])[t] = 0;
+    __syncthreads();
+    uint32_t first, last;
+    gsx_block_tiles((count + TILE - 1) / TILE, gridDim.x, blockIdx.x, first, last);
+    uint32_t* wh = s_whist[threadIdx.x >> 6];
+    const uint64_t begin = static_cast<uint64_t>(first) * TILE, end = min(static_cast<uint64_t>(last) * TILE, static_cast<uint64_t>(count));
+    // whole waves stay in the loop together (begin is a multiple of 64*...), tail lanes are masked
+    for (uint64_t base = begin; base < end; base += static_cast<uint64_t>(NT) * 4) {
+        KeyT k[4];
+        bool ok[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint64_t g = base + static_cast<uint64_t>(j) * NT + threadIdx.x;
+            ok[j] = g < end;
+            k[j] = ok[j] ? keys[g] : static_cast<KeyT>(0);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            // padding lanes take digit `nd` .. never: give them their own pseudo digit by clearing them from the peers
+            const uint32_t d = (static_cast<uint32_t>(k[j]) >> shift) & mask;
+            const uint64_t live = __builtin_amdgcn_ballot_w64(ok[j]);
+            const uint64_t peers = gsx_match_digit(d, bits) & live;
+            if (ok[j] && gsx_mbcnt(peers) == 0) atomicAdd(&wh[d], static_cast<uint32_t>(__popcll(peers)));
+        }
+    }
+    gsx_hist_flush<NT>(s_whist, nd, cnt);
+}
+
+// ---- S: per digit, exclusive scan over blocks (in place) + digit total --------
+template <int DUMMY>
+__global__ __launch_bounds__(256) void k_radix_scan(uint32_t* __restrict__ cnt, uint32_t g, uint32_t* __restrict__ totals) {
+    __shared__ uint32_t s_tmp[4];
+    uint32_t* row = cnt + static_cast<uint64_t>(blockIdx.x) * g;
+    constexpr int PER = GSX_RADIX_MAX_BLOCKS / 256;   // 8 consecutive entries per thread
+    uint32_t v[PER], sum = 0;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const uint32_t i = threadIdx.x * PER + j;
+        v[j] = (i < g) ? row[i] : 0u;
+        sum += v[j];
+    }
+    uint32_t total;
+    uint32_t run = gsx_block_excl_scan<256>(sum, s_tmp, &total);
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const uint32_t i = threadIdx.x * PER + j;
+        if (i < g) row[i] = run;
+        run += v[j];
+    }
+    if (threadIdx.x == 0) totals[blockIdx.x] = total;
+}
+
+// ---- X: rank + scatter ---------------------------------------------------------
+template <typename KeyT, int NT, int IPT, bool IOTA_VALS>
+__global__ __launch_bounds__(NT) void k_radix_scatter(const KeyT* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
+                                                      KeyT* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
+                                                      const uint32_t* __restrict__ count_ptr, uint32_t shift, uint32_t bits,
+                                                      const uint32_t* __restrict__ cnt_scanned, const uint32_t* __restrict__ totals) {
+    constexpr int NW = NT / 64;
+    constexpr int TILE = NT * IPT;
+    __shared__ KeyT s_keys[TILE];
+    __shared__ uint32_t s_vals[TILE];
+    __shared__ uint32_t s_whist[NW][GSX_RADIX_MAX_DIGITS];   // per-wave digit counts, then wave prefixes + bin base
+    __shared__ uint32_t s_gofs[GSX_RADIX_MAX_DIGITS];        // global index = s_gofs[d] + LDS slot
+    __shared__ uint32_t s_run[GSX_RADIX_MAX_DIGITS];         // next free global slot of digit d for this block
+    __shared__ uint32_t s_tmp[NW];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t nd = 1u << bits, mask = nd - 1u;
+    const uint32_t count = *count_ptr;
+    uint32_t first, last;
+    gsx_block_tiles((count + TILE - 1) / TILE, gridDim.x, blockIdx.x, first, last);
+    if (first >= last) return;
+
+    // running offsets: exclusive scan of the digit totals + this block's scanned count.
+    // Thread t owns the PER consecutive digits t*PER .. t*PER+PER-1.
+    constexpr int PER = GSX_RADIX_MAX_DIGITS / NT;
+    static_assert(PER >= 1 && PER * NT == GSX_RADIX_MAX_DIGITS, "NT must divide the digit count");
+    {
+        uint32_t tot[PER], sum = 0;
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            const uint32_t d = tid * PER + j;
+            tot[j] = (d < nd) ? totals[d] : 0u;
+            sum += tot[j];
+        }
+        uint32_t run = gsx_block_excl_scan<NT>(sum, s_tmp, nullptr);
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            const uint32_t d = tid * PER + j;
+            if (d < nd) s_run[d] = run + cnt_scanned[static_cast<uint64_t>(d) * gridDim.x + blockIdx.x];
+            run += tot[j];
+        }
+    }
+    __syncthreads();
+
+    for (uint32_t tile = first; tile < last; ++tile) {
+        const uint32_t tile_base = tile * TILE;
+        const uint32_t wave_base = tile_base + wave * (64 * IPT);
+        // ---- load keys and values together (wave-striped: item i of lane l = wave_base + i*64 + l) ----
+        KeyT key[IPT];
+        uint32_t val[IPT];
+#pragma unroll
+        for (int i = 0; i < IPT; ++i) {
+            const uint32_t g = wave_base + i * 64 + lane;
+            key[i] = (g < count) ? keys_in[g] : static_cast<KeyT>(~static_cast<KeyT>(0));
+            val[i] = IOTA_VALS ? g : ((g < count) ? vals_in[g] : 0u);
+        }
+        for (uint32_t t = tid; t < NW * GSX_RADIX_MAX_DIGITS; t += NT) (&s_whist[0][0])[t] = 0;
+        __syncthreads();   // also: previous tile's write-out has finished reading s_keys/s_vals/s_gofs
+
+        // ---- rank inside the wave: ballots + one returning LDS add per (item, digit) ----
+        uint32_t* wh = s_whist[wave];
+        uint32_t lead_prev[IPT];
+        uint16_t lower[IPT];
+        uint8_t leader[IPT];
+#pragma unroll
+        for (int i = 0; i < IPT; ++i) {
+            const uint32_t d = (static_cast<uint32_t>(key[i]) >> shift) & mask;
+            const uint64_t peers = gsx_match_digit(d, bits);
+            lower[i] = static_cast<uint16_t>(gsx_mbcnt(peers));
+            leader[i] = static_cast<uint8_t>(__builtin_ctzll(peers));
+            lead_prev[i] = 0;
+            if (lower[i] == 0) lead_prev[i] = atomicAdd(&wh[d], static_cast<uint32_t>(__popcll(peers)));
+        }
+        uint16_t rank[IPT];
+#pragma unroll
+        for (int i = 0; i < IPT; ++i) rank[i] = static_cast<uint16_t>(__shfl(lead_prev[i], leader[i]) + lower[i]);
+        __syncthreads();
+
+        // ---- per digit: prefix over waves, bin base, global offset ----
+        {
+            uint32_t acc[PER], sum = 0;
+#pragma unroll
+            for (int j = 0; j < PER; ++j) {
+                const uint32_t d = tid * PER + j;
+                acc[j] = 0;
+                if (d < nd) {
+#pragma unroll
+                    for (int w = 0; w < NW; ++w) acc[j] += s_whist[w][d];
+                }
+                sum += acc[j];
+            }
+            uint32_t bin_base = gsx_block_excl_scan<NT>(sum, s_tmp, nullptr);
+#pragma unroll
+            for (int j = 0; j < PER; ++j) {
+                const uint32_t d = tid * PER + j;
+                if (d < nd) {
+                    uint32_t pre = bin_base;
+#pragma unroll
+                    for (int w = 0; w < NW; ++w) {
+                        const uint32_t c = s_whist[w][d];
+                        s_whist[w][d] = pre;       // bin base + counts of the lower waves
+                        pre += c;
+                    }
+                    s_gofs[d] = s_run[d] - bin_base;
+                    s_run[d] += acc[j];
+                }
+                bin_base += acc[j];
+            }
+        }
+        __syncthreads();
+
+        // ---- scatter into LDS in digit order ----
+#pragma unroll
+        for (int i = 0; i < IPT; ++i) {
+            const uint32_t d = (static_cast<uint32_t>(key[i]) >> shift) & mask;
+            const uint32_t pos = s_whist[wave][d] + rank[i];
+            s_keys[pos] = key[i];
+            s_vals[pos] = val[i];
+        }
+        __syncthreads();
+
+        // ---- write-out: consecutive LDS slots of one digit are consecutive in HBM ----
+        const uint32_t valid = (count - tile_base < static_cast<uint32_t>(TILE)) ? (count - tile_base) : TILE;
+#pragma unroll
+        for (int i = 0; i < IPT; ++i) {
+            const uint32_t p = i * NT + tid;
+            if (p < valid) {
+                const KeyT k = s_keys[p];
+                const uint32_t d = (static_cast<uint32_t>(k) >> shift) & mask;
+                const uint32_t dst = s_gofs[d] + p;
+                keys_out[dst] = k;
+                vals_out[dst] = s_vals[p];
+            }
+        }
+    }
+}
+
+// ---- host side -------------------------------------------------------------------
+struct GsxRadixPlan {
+    int n_passes = 0;
+    uint32_t shift[4] = {0, 0, 0, 0};
+    uint32_t bits[4] = {0, 0, 0, 0};
+};
+
+// Split `total_bits` key bits into the fewest passes of at most GSX_RADIX_MAX_BITS bits, balanced.
+static inline GsxRadixPlan gsx_radix_plan(uint32_t total_bits) {
+    GsxRadixPlan p;
+    if (total_bits == 0) total_bits = 1;
+    p.n_passes = static_cast<int>((total_bits + GSX_RADIX_MAX_BITS - 1) / GSX_RADIX_MAX_BITS);
+    uint32_t left = total_bits, shift = 0;
+    for (int i = 0; i < p.n_passes; ++i) {
+        const uint32_t b = (left + (p.n_passes - i) - 1) / (p.n_passes - i);
+        p.shift[i] = shift;
+        p.bits[i] = b;
+        shift += b;
+        left -= b;
+    }
+    return p;
+}
+
+static inline uint32_t gsx_radix_blocks(uint64_t cap, uint32_t tile) {
+    const uint64_t t = (cap + tile - 1) / tile;
+    return static_cast<uint32_t>(t < 1 ? 1 : (t > GSX_RADIX_MAX_BLOCKS ? GSX_RADIX_MAX_BLOCKS : t));
+}
+// bytes of the count matrix + totals for one sort of up to `cap` keys
+static inline uint64_t gsx_radix_workspace_words(uint32_t blocks) {
+    return static_cast<uint64_t>(GSX_RADIX_MAX_DIGITS) * blocks + GSX_RADIX_MAX_DIGITS;
+}

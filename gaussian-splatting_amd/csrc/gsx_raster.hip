@@ -13,8 +13,8 @@
 // parallelogram at constant clip w, uv is an affine function of the pixel
 // position, so coverage + uv come from one 2x2 inverse instead of triangle
 // setup.  The binner expands the depth-sorted permutation into (tile, splat)
-// pairs in rank order and a stable 2-pass radix sort by tile id (same onesweep
-// pass as the depth sort) yields per-tile lists that preserve depth order.
+// pairs in rank order and a stable 2-pass radix sort by tile id (the same radix
+// passes as the depth sort) yields per-tile lists that preserve depth order.
 // The rasterizer composites each 16x16 tile in sorted order, walking the list
 // from the NEAR end with a transmittance accumulator
 //     C = sum_i c_i a_i prod_{j nearer than i} (1 - a_j)  +  T_final * clear
@@ -22,7 +22,7 @@
 // tile stop as soon as every pixel's transmittance is below 2^-11 (bounded
 // error < 0.13/255).
 #include "gsx_internal.h"
-#include "gsx_onesweep.hpp"
+#include "gsx_radix.hpp"
 
 struct GsxViewParams {
     float wt[16];      // view * model
@@ -141,19 +141,14 @@ __device__ __forceinline__ bool gsx_tile_bbox(float4 c, const GsxViewParams& vp,
 #define GSX_BIN_IPT 4
 #define GSX_BIN_TILE (GSX_BIN_NT * GSX_BIN_IPT)
 
-__device__ __forceinline__ const uint32_t* gsx_sorted(const GsxSortPlan* plan, const uint32_t* v0, const uint32_t* v1) {
-    return plan->final_buf ? v1 : v0;
-}
-
 template <bool EMIT, bool RANK_PAYLOAD>
-__global__ __launch_bounds__(GSX_BIN_NT) void k_bin(const GsxSortPlan* __restrict__ plan, const uint32_t* __restrict__ v0,
-                                                    const uint32_t* __restrict__ v1, const GsxProj* __restrict__ proj,
+__global__ __launch_bounds__(GSX_BIN_NT) void k_bin(const uint32_t* __restrict__ m_ptr, const uint32_t* __restrict__ sorted,
+                                                    const GsxProj* __restrict__ proj,
                                                     GsxViewParams vp, uint32_t* __restrict__ block_sums,
                                                     uint16_t* __restrict__ pair_key, uint32_t* __restrict__ pair_val,
                                                     uint64_t pair_cap, GsxDevFlags* __restrict__ flags) {
     __shared__ uint32_t s_tmp[GSX_BIN_NT / 64];
-    const uint32_t m = plan->m;
-    const uint32_t* sorted = gsx_sorted(plan, v0, v1);
+    const uint32_t m = *m_ptr;
     uint32_t cnt[GSX_BIN_IPT], idx[GSX_BIN_IPT], bx0[GSX_BIN_IPT], bx1[GSX_BIN_IPT], by0[GSX_BIN_IPT], by1[GSX_BIN_IPT];
     uint32_t tot = 0;
     // thread t owns ranks base + t*IPT .. +IPT-1 so that pairs come out in rank order
@@ -210,63 +205,7 @@ __global__ __launch_bounds__(1024) void k_scan_sums(uint32_t* __restrict__ sums,
     if (threadIdx.x == 0) *total_out = s_carry;
 }
 
-// ---------------------------------------------------------------------------
-// K4c: stable radix sort of the pairs by 16-bit tile id (1 or 2 onesweep passes).
-// ---------------------------------------------------------------------------
-struct GsxPairZero {
-    uint32_t ghist[2][GSX_RADIX];
-    uint32_t tile_ctr[2];
-    uint32_t pad[14];
-};
-
-__global__ __launch_bounds__(256) void k_pair_hist(const uint16_t* __restrict__ keys, uint32_t count,
-                                                   uint32_t* __restrict__ ghist) {
-    __shared__ uint32_t sh[2][GSX_RADIX];
-    for (uint32_t t = threadIdx.x; t < 2 * GSX_RADIX; t += blockDim.x) (&sh[0][0])[t] = 0;
-    __syncthreads();
-    const uint32_t stride = gridDim.x * blockDim.x;
-    for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < count; k += stride) {
-        const uint32_t key = keys[k];
-        atomicAdd(&sh[0][key & 0xFFu], 1u);
-        atomicAdd(&sh[1][key >> 8], 1u);
-    }
-    __syncthreads();
-    for (uint32_t t = threadIdx.x; t < 2 * GSX_RADIX; t += blockDim.x) {
-        const uint32_t v = (&sh[0][0])[t];
-        if (v) atomicAdd(&ghist[t], v);
-    }
-}
-
-__global__ __launch_bounds__(256) void k_pair_scan_hist(GsxPairZero* __restrict__ z, uint32_t* __restrict__ gbase /*2x256*/) {
-    __shared__ uint32_t s_tmp[4];
-    for (int p = 0; p < 2; ++p) gbase[p * GSX_RADIX + threadIdx.x] = gsx_block_excl_scan<256>(z->ghist[p][threadIdx.x], s_tmp, nullptr);
-}
-
-#define GSX_PAIR_NT 256
-#define GSX_PAIR_IPT 16
-#define GSX_PAIR_TILE (GSX_PAIR_NT * GSX_PAIR_IPT)
-
-__global__ __launch_bounds__(GSX_PAIR_NT) void k_pair_pass(const uint16_t* __restrict__ kin, const uint32_t* __restrict__ vin,
-                                                           uint16_t* __restrict__ kout, uint32_t* __restrict__ vout,
-                                                           uint32_t count, int pass, GsxPairZero* __restrict__ z,
-                                                           const uint32_t* __restrict__ gbase, uint32_t* __restrict__ status,
-                                                           uint32_t* __restrict__ spin_flag) {
-    __shared__ uint16_t s_keys[GSX_PAIR_TILE];
-    __shared__ uint32_t s_vals[GSX_PAIR_TILE];
-    __shared__ uint32_t s_whist[GSX_PAIR_NT / 64][GSX_RADIX];
-    __shared__ uint32_t s_binbase[GSX_RADIX];
-    __shared__ uint32_t s_gofs[GSX_RADIX];
-    __shared__ uint32_t s_tmp[GSX_PAIR_NT / 64];
-    __shared__ uint32_t s_tile;
-    if (threadIdx.x == 0) s_tile = atomicAdd(&z->tile_ctr[pass], 1u);
-    for (uint32_t t = threadIdx.x; t < (GSX_PAIR_NT / 64) * GSX_RADIX; t += GSX_PAIR_NT) (&s_whist[0][0])[t] = 0;
-    __syncthreads();
-    const uint32_t tile = s_tile;
-    if (static_cast<uint64_t>(tile) * GSX_PAIR_TILE >= count) return;
-    gsx_onesweep_tile<uint16_t, GSX_PAIR_NT, GSX_PAIR_IPT, false>(kin, vin, kout, vout, count, 8u * pass, tile, status,
-                                                                  gbase + pass * GSX_RADIX, spin_flag, s_keys, s_vals, s_whist,
-                                                                  s_binbase, s_gofs, s_tmp);
-}
+// K4c (stable radix sort of the pairs by 16-bit tile id) uses gsx_radix.hpp.
 
 // tile_start[t] = lower_bound(sorted pair keys, t), t in [0, n_tiles]
 __global__ __launch_bounds__(256) void k_tile_ranges(const uint16_t* __restrict__ keys, uint32_t count, uint32_t n_tiles,
@@ -318,8 +257,7 @@ __device__ __forceinline__ uint32_t gsx_bayer(uint32_t x, uint32_t y, uint32_t b
 
 template <int MODE /*0 blend, 1 threshold (bayerSize 10), 2 bayer dither*/>
 __global__ __launch_bounds__(256) void k_raster(const uint32_t* __restrict__ tile_start, const uint32_t* __restrict__ pair_val,
-                                                const GsxProj* __restrict__ proj, const GsxSortPlan* __restrict__ plan,
-                                                const uint32_t* __restrict__ v0, const uint32_t* __restrict__ v1,
+                                                const GsxProj* __restrict__ proj, const uint32_t* __restrict__ sorted_all,
                                                 GsxViewParams vp, uint8_t* __restrict__ fb) {
     __shared__ float4 s_a[GSX_RASTER_BATCH];  // cx cy ex ey
     __shared__ float4 s_m[GSX_RASTER_BATCH];  // m00 m01 m10 m11
@@ -337,7 +275,7 @@ __global__ __launch_bounds__(256) void k_raster(const uint32_t* __restrict__ til
     const float wx0 = static_cast<float>(tx * GSX_TILE_W + qx) + 0.5f, wx1 = wx0 + 7.0f;
     const float wy0 = static_cast<float>(ty * GSX_TILE_H + qy) + 0.5f, wy1 = wy0 + 7.0f;
     const bool inside = (px < static_cast<uint32_t>(vp.width)) && (py >= vp.y0) && (py < vp.y1);
-    const uint32_t* sorted = (MODE == 2) ? gsx_sorted(plan, v0, v1) : nullptr;
+    const uint32_t* sorted = sorted_all;   // only read in MODE 2 (pairs then carry ranks)
 
     float T = inside ? 1.0f : 0.0f, cr = 0.0f, cg = 0.0f, cb = 0.0f;
     const uint32_t begin = tile_start[tile], end = tile_start[tile + 1];
@@ -458,6 +396,8 @@ int gsx_launch_render(gsx_ctx* c, const gsx_uniforms* u, uint32_t w, uint32_t h,
     const uint32_t nb_bin = gsx_div_up(m_cap, GSX_BIN_TILE);
     if ((rc = ensure(c, &c->scan_block_sums, &c->rank_cap, static_cast<uint64_t>(nb_bin) + 1)) != GSX_OK) return rc;
 
+    const uint32_t* sorted = c->vals[c->sorted_buf];
+
     // K3
     if (c->profiling) GSX_HIP(c, hipEventRecord(c->ev[EV_PROJ0], c->stream));
     if (n > 0)
@@ -468,12 +408,12 @@ int gsx_launch_render(gsx_ctx* c, const gsx_uniforms* u, uint32_t w, uint32_t h,
     // K4a: count
     uint32_t total_pairs = 0;
     if (nb_bin > 0) {
-        hipLaunchKernelGGL((k_bin<false, false>), dim3(nb_bin), dim3(GSX_BIN_NT), 0, c->stream, c->plan, c->vals[0],
-                           c->vals[1], c->proj, vp, c->scan_block_sums, nullptr, nullptr, 0ull, c->flags);
+        hipLaunchKernelGGL((k_bin<false, false>), dim3(nb_bin), dim3(GSX_BIN_NT), 0, c->stream, c->m_dev, sorted, c->proj, vp,
+                           c->scan_block_sums, nullptr, nullptr, 0ull, c->flags);
         hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, c->stream, c->scan_block_sums, nb_bin, c->pair_total_dev);
-        GSX_HIP(c, hipMemcpyAsync(&c->plan_host->pad, c->pair_total_dev, 4, hipMemcpyDeviceToHost, c->stream));
+        GSX_HIP(c, hipMemcpyAsync(c->host_word, c->pair_total_dev, 4, hipMemcpyDeviceToHost, c->stream));
         GSX_HIP(c, hipStreamSynchronize(c->stream));
-        total_pairs = c->plan_host->pad;
+        total_pairs = *c->host_word;
     }
     c->tim.tile_pairs = total_pairs;
     const uint16_t* sorted_keys = nullptr;
@@ -489,34 +429,28 @@ int gsx_launch_render(gsx_ctx* c, const gsx_uniforms* u, uint32_t w, uint32_t h,
         if (cap3 < c->pair_cap) c->pair_cap = cap3;
         // K4b: emit
         if (mode == 2)
-            hipLaunchKernelGGL((k_bin<true, true>), dim3(nb_bin), dim3(GSX_BIN_NT), 0, c->stream, c->plan, c->vals[0],
-                               c->vals[1], c->proj, vp, c->scan_block_sums, c->pair_key[0], c->pair_val[0], c->pair_cap, c->flags);
+            hipLaunchKernelGGL((k_bin<true, true>), dim3(nb_bin), dim3(GSX_BIN_NT), 0, c->stream, c->m_dev, sorted, c->proj, vp,
+                               c->scan_block_sums, c->pair_key[0], c->pair_val[0], c->pair_cap, c->flags);
         else
-            hipLaunchKernelGGL((k_bin<true, false>), dim3(nb_bin), dim3(GSX_BIN_NT), 0, c->stream, c->plan, c->vals[0],
-                               c->vals[1], c->proj, vp, c->scan_block_sums, c->pair_key[0], c->pair_val[0], c->pair_cap, c->flags);
-        // K4c: sort pairs by tile id
-        const int n_pass = (n_tiles > 256u) ? 2 : 1;
-        const uint32_t n_ptiles = gsx_div_up(total_pairs, GSX_PAIR_TILE);
-        const uint64_t status_words = static_cast<uint64_t>(n_ptiles) * GSX_RADIX;
-        const uint64_t zbytes = sizeof(GsxPairZero) + 2 * GSX_RADIX * 4 + static_cast<uint64_t>(n_pass) * status_words * 4;
-        {
-            uint8_t* z = static_cast<uint8_t*>(c->bin_zero);
-            uint64_t cap = c->bin_zero_bytes;
-            if ((rc = ensure(c, &z, &cap, zbytes)) != GSX_OK) return rc;
-            c->bin_zero = z; c->bin_zero_bytes = cap;
-        }
-        GsxPairZero* z = static_cast<GsxPairZero*>(c->bin_zero);
-        uint32_t* gbase = reinterpret_cast<uint32_t*>(z + 1);
-        uint32_t* status0 = gbase + 2 * GSX_RADIX;
-        GSX_HIP(c, hipMemsetAsync(c->bin_zero, 0, zbytes, c->stream));
-        hipLaunchKernelGGL(k_pair_hist, dim3(min(gsx_div_up(total_pairs, 256 * 8), 2048u)), dim3(256), 0, c->stream,
-                           c->pair_key[0], total_pairs, &z->ghist[0][0]);
-        hipLaunchKernelGGL(k_pair_scan_hist, dim3(1), dim3(256), 0, c->stream, z, gbase);
+            hipLaunchKernelGGL((k_bin<true, false>), dim3(nb_bin), dim3(GSX_BIN_NT), 0, c->stream, c->m_dev, sorted, c->proj, vp,
+                               c->scan_block_sums, c->pair_key[0], c->pair_val[0], c->pair_cap, c->flags);
+        // K4c: stable sort of the pairs by tile id
+        uint32_t tile_bits = 1;
+        while ((1u << tile_bits) < n_tiles) ++tile_bits;
+        const GsxRadixPlan plan = gsx_radix_plan(tile_bits);
+        const uint32_t g = gsx_radix_blocks(total_pairs, GSX_PAIR_TILE);
+        if ((rc = ensure(c, &c->pair_ws, &c->pair_ws_words, gsx_radix_workspace_words(g))) != GSX_OK) return rc;
+        GSX_HIP(c, hipMemcpyAsync(c->pair_total_dev, c->host_word, 4, hipMemcpyHostToDevice, c->stream));  // (already there; keeps count_ptr explicit)
+        uint32_t* cnt = c->pair_ws;
+        uint32_t* totals = cnt + static_cast<uint64_t>(GSX_RADIX_MAX_DIGITS) * g;
         int cur = 0;
-        for (int p = 0; p < n_pass; ++p) {
-            hipLaunchKernelGGL(k_pair_pass, dim3(n_ptiles), dim3(GSX_PAIR_NT), 0, c->stream, c->pair_key[cur], c->pair_val[cur],
-                               c->pair_key[cur ^ 1], c->pair_val[cur ^ 1], total_pairs, p, z, gbase,
-                               status0 + static_cast<uint64_t>(p) * status_words, &c->flags->spin_expired);
+        for (int p = 0; p < plan.n_passes; ++p) {
+            hipLaunchKernelGGL((k_radix_hist<uint16_t, GSX_PAIR_NT, GSX_PAIR_IPT>), dim3(g), dim3(GSX_PAIR_NT), 0, c->stream,
+                               c->pair_key[cur], c->pair_total_dev, plan.shift[p], plan.bits[p], cnt);
+            hipLaunchKernelGGL((k_radix_scan<0>), dim3(1u << plan.bits[p]), dim3(256), 0, c->stream, cnt, g, totals);
+            hipLaunchKernelGGL((k_radix_scatter<uint16_t, GSX_PAIR_NT, GSX_PAIR_IPT, false>), dim3(g), dim3(GSX_PAIR_NT), 0, c->stream,
+                               c->pair_key[cur], c->pair_val[cur], c->pair_key[cur ^ 1], c->pair_val[cur ^ 1], c->pair_total_dev,
+                               plan.shift[p], plan.bits[p], cnt, totals);
             cur ^= 1;
         }
         sorted_keys = c->pair_key[cur];
@@ -531,14 +465,14 @@ int gsx_launch_render(gsx_ctx* c, const gsx_uniforms* u, uint32_t w, uint32_t h,
     // K5
     if (n_tiles > 0) {
         if (mode == 0)
-            hipLaunchKernelGGL(k_raster<0>, dim3(n_tiles), dim3(256), 0, c->stream, c->tile_start, sorted_vals, c->proj, c->plan,
-                               c->vals[0], c->vals[1], vp, c->fb);
+            hipLaunchKernelGGL(k_raster<0>, dim3(n_tiles), dim3(256), 0, c->stream, c->tile_start, sorted_vals, c->proj, sorted,
+                               vp, c->fb);
         else if (mode == 1)
-            hipLaunchKernelGGL(k_raster<1>, dim3(n_tiles), dim3(256), 0, c->stream, c->tile_start, sorted_vals, c->proj, c->plan,
-                               c->vals[0], c->vals[1], vp, c->fb);
+            hipLaunchKernelGGL(k_raster<1>, dim3(n_tiles), dim3(256), 0, c->stream, c->tile_start, sorted_vals, c->proj, sorted,
+                               vp, c->fb);
         else
-            hipLaunchKernelGGL(k_raster<2>, dim3(n_tiles), dim3(256), 0, c->stream, c->tile_start, sorted_vals, c->proj, c->plan,
-                               c->vals[0], c->vals[1], vp, c->fb);
+            hipLaunchKernelGGL(k_raster<2>, dim3(n_tiles), dim3(256), 0, c->stream, c->tile_start, sorted_vals, c->proj, sorted,
+                               vp, c->fb);
     }
     if (c->profiling) GSX_HIP(c, hipEventRecord(c->ev[EV_RAST1], c->stream));
     GSX_HIP(c, hipGetLastError());

@@ -4,7 +4,10 @@
 // Reference path replaced: SplatMesh::sortSplats (SplatMesh.h:84-114) and the
 // per-frame index upload (SplatMesh.h:56-57).
 #include "gsx_internal.h"
-#include "gsx_onesweep.hpp"
+#include "gsx_radix.hpp"
+
+#include <cmath>
+#include <cstring>
 
 // ---------------------------------------------------------------------------
 // Upload: 80-B AoS `Splat` (Splat.h:19-29) -> SoA float4 arrays.
@@ -51,58 +54,59 @@ __device__ __forceinline__ float gsx_distance(float4 p, float cx, float cy, floa
 }
 __device__ __forceinline__ uint32_t gsx_key_from_distance(float d) { return (~__float_as_uint(d)) & 0x7FFFFFFFu; }
 
-// LDS histogram add with a wave-uniform fast path (the high digits of distance
-// keys are nearly constant, which would serialise 64-way on one LDS word).
-__device__ __forceinline__ void gsx_hist_add(uint32_t* hist, uint32_t d, bool active) {
-    const uint64_t act = __builtin_amdgcn_ballot_w64(active);
-    if (act == 0) return;
-    const uint32_t first = static_cast<uint32_t>(__builtin_ctzll(act));
-    const uint32_t d0 = __shfl(d, first);
-    const uint64_t same = __builtin_amdgcn_ballot_w64(active && d == d0);
-    if (same == act) {
-        if (gsx_lane() == first) atomicAdd(&hist[d0], static_cast<uint32_t>(__popcll(act)));
-    } else if (active) {
-        atomicAdd(&hist[d], 1u);
-    }
-}
-
+// ---------------------------------------------------------------------------
+// K1: depth keys of the selection + the digit counts of radix pass 0 (fused H0).
+// Block b owns the same contiguous tile range the radix passes give it.  Keys are
+// stored relative to key_lo (the key of the host-computed upper distance bound),
+// which makes the number of significant key bits — and so the number of radix
+// passes — a host-side constant for the frame.
+// ---------------------------------------------------------------------------
 template <bool IOTA>
-__global__ __launch_bounds__(256) void k_keygen_hist(const float4* __restrict__ pos4, const uint32_t* __restrict__ sel,
-                                                     const uint32_t* __restrict__ m_ptr, float cx, float cy, float cz,
-                                                     uint32_t* __restrict__ keys, uint32_t* __restrict__ ghist) {
-    __shared__ uint32_t sh[GSX_PASSES][GSX_RADIX];
-    for (uint32_t t = threadIdx.x; t < GSX_PASSES * GSX_RADIX; t += blockDim.x) (&sh[0][0])[t] = 0;
-    __syncthreads();
+__global__ __launch_bounds__(GSX_SORT_NT) void k_keygen_hist0(const float4* __restrict__ pos4, const uint32_t* __restrict__ sel,
+                                                              const uint32_t* __restrict__ m_ptr, float cx, float cy, float cz,
+                                                              uint32_t key_lo, uint32_t key_span, uint32_t shift, uint32_t bits,
+                                                              uint32_t* __restrict__ keys, uint32_t* __restrict__ cnt,
+                                                              GsxDevFlags* __restrict__ flags) {
+    __shared__ uint32_t s_whist[GSX_SORT_NT / 64][GSX_RADIX_MAX_DIGITS];
+    const uint32_t nd = 1u << bits, mask = nd - 1u;
     const uint32_t m = *m_ptr;
+    for (uint32_t t = threadIdx.x; t < (GSX_SORT_NT / 64) * GSX_RADIX_MAX_DIGITS; t += GSX_SORT_NT) (&s_whist[0][0])[t] = 0;
+    __syncthreads();
+    uint32_t first, last;
+    gsx_block_tiles((m + GSX_SORT_TILE - 1) / GSX_SORT_TILE, gridDim.x, blockIdx.x, first, last);
+    uint32_t* wh = s_whist[threadIdx.x >> 6];
+    const uint64_t begin = static_cast<uint64_t>(first) * GSX_SORT_TILE;
+    const uint64_t end = min(static_cast<uint64_t>(last) * GSX_SORT_TILE, static_cast<uint64_t>(m));
     constexpr int UNROLL = 4;
-    const uint32_t stride = gridDim.x * blockDim.x;
-    // Lanes whose k0 runs past m leave the loop; ballots below only see live lanes.
-    for (uint32_t k0 = blockIdx.x * blockDim.x + threadIdx.x; k0 < m; k0 += stride * UNROLL) {
+    for (uint64_t base = begin; base < end; base += static_cast<uint64_t>(GSX_SORT_NT) * UNROLL) {
         float4 p[UNROLL];
         bool ok[UNROLL];
 #pragma unroll
         for (int j = 0; j < UNROLL; ++j) {
-            const uint64_t k = static_cast<uint64_t>(k0) + static_cast<uint64_t>(j) * stride;
-            ok[j] = k < m;
+            const uint64_t k = base + static_cast<uint64_t>(j) * GSX_SORT_NT + threadIdx.x;
+            ok[j] = k < end;
             if (ok[j]) p[j] = pos4[IOTA ? static_cast<uint32_t>(k) : sel[k]];
         }
 #pragma unroll
         for (int j = 0; j < UNROLL; ++j) {
-            const uint64_t k = static_cast<uint64_t>(k0) + static_cast<uint64_t>(j) * stride;
-            uint32_t key = 0;
+            const uint64_t k = base + static_cast<uint64_t>(j) * GSX_SORT_NT + threadIdx.x;
+            uint32_t rel = 0;
             if (ok[j]) {
-                key = gsx_key_from_distance(gsx_distance(p[j], cx, cy, cz));
-                keys[k] = key;
+                const uint32_t key = gsx_key_from_distance(gsx_distance(p[j], cx, cy, cz));
+                rel = key - key_lo;
+                if (key < key_lo || rel > key_span) {   // outside the bound: NaN/inf position
+                    atomicOr(&flags->key_bound, 1u);
+                    rel = (key < key_lo) ? 0u : key_span;
+                }
+                keys[k] = rel;
             }
-#pragma unroll
-            for (int q = 0; q < GSX_PASSES; ++q) gsx_hist_add(sh[q], (key >> (8 * q)) & 0xFFu, ok[j]);
+            const uint32_t d = (rel >> shift) & mask;
+            const uint64_t live = __builtin_amdgcn_ballot_w64(ok[j]);
+            const uint64_t peers = gsx_match_digit(d, bits) & live;
+            if (ok[j] && gsx_mbcnt(peers) == 0) atomicAdd(&wh[d], static_cast<uint32_t>(__popcll(peers)));
         }
     }
-    __syncthreads();
-    for (uint32_t t = threadIdx.x; t < GSX_PASSES * GSX_RADIX; t += blockDim.x) {
-        const uint32_t v = (&sh[0][0])[t];
-        if (v) atomicAdd(&ghist[t], v);
-    }
+    gsx_hist_flush<GSX_SORT_NT>(s_whist, nd, cnt);
 }
 
 // Distances only (parity aid for gsx_get_keys).
@@ -115,99 +119,121 @@ __global__ __launch_bounds__(256) void k_distances(const float4* __restrict__ po
     out[k] = gsx_distance(pos4[IOTA ? k : sel[k]], cx, cy, cz);
 }
 
-// One block: exclusive scans of the four global histograms + which passes to run.
-__global__ __launch_bounds__(256) void k_sort_plan(const uint32_t* __restrict__ ghist, const uint32_t* __restrict__ m_ptr,
-                                                   GsxSortPlan* __restrict__ plan) {
-    __shared__ uint32_t s_tmp[4];
-    __shared__ uint32_t s_skip[GSX_PASSES];
-    const uint32_t tid = threadIdx.x, m = *m_ptr;
-    if (tid < GSX_PASSES) s_skip[tid] = 0;
-    __syncthreads();
-    for (int p = 0; p < GSX_PASSES; ++p) {
-        const uint32_t v = ghist[p * GSX_RADIX + tid];
-        if (p > 0 && m > 0 && v == m) s_skip[p] = 1;  // pass 0 always runs: it materialises the index payload
-        plan->gbase[p][tid] = gsx_block_excl_scan<256>(v, s_tmp, nullptr);
+// Axis-aligned bounds of the uploaded positions (ordered-int atomics), used by the
+// host to bound the distance range of a frame.
+__device__ __forceinline__ int gsx_f2ord(float f) { const int i = __float_as_int(f); return i >= 0 ? i : i ^ 0x7FFFFFFF; }
+__global__ __launch_bounds__(256) void k_aabb(const float4* __restrict__ pos4, uint64_t n, int* __restrict__ out6) {
+    int mn[3] = {0x7FFFFFFF, 0x7FFFFFFF, 0x7FFFFFFF}, mx[3] = {(int)0x80000000, (int)0x80000000, (int)0x80000000};
+    for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += static_cast<uint64_t>(gridDim.x) * blockDim.x) {
+        const float4 p = pos4[i];
+        const float v[3] = {p.x, p.y, p.z};
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            if (v[k] == v[k]) { const int o = gsx_f2ord(v[k]); mn[k] = min(mn[k], o); mx[k] = max(mx[k], o); }
     }
-    __syncthreads();
-    if (tid == 0) {
-        uint32_t cur = 1, run = 1;  // pass 0: keys[0] -> keys[1]
-        plan->skip[0] = 0;
-        plan->src[0] = 0;
-        for (int p = 1; p < GSX_PASSES; ++p) {
-            plan->skip[p] = s_skip[p];
-            plan->src[p] = cur;
-            if (!s_skip[p]) { cur ^= 1u; ++run; }
-        }
-        plan->final_buf = cur;
-        plan->m = m;
-        plan->passes_run = run;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { mn[k] = min(mn[k], __shfl_xor(mn[k], off)); mx[k] = max(mx[k], __shfl_xor(mx[k], off)); }
+        if ((threadIdx.x & 63) == 0) { atomicMin(&out6[k], mn[k]); atomicMax(&out6[3 + k], mx[k]); }
     }
 }
 
-template <bool IOTA>
-__global__ __launch_bounds__(GSX_SORT_NT) void k_sort_pass(uint32_t* __restrict__ k0, uint32_t* __restrict__ k1,
-                                                           uint32_t* __restrict__ v0, uint32_t* __restrict__ v1,
-                                                           const uint32_t* __restrict__ sel, int pass,
-                                                           const GsxSortPlan* __restrict__ plan,
-                                                           GsxSortZero* __restrict__ zero, uint32_t* __restrict__ status,
-                                                           uint32_t* __restrict__ spin_flag) {
-    __shared__ uint32_t s_keys[GSX_SORT_TILE];
-    __shared__ uint32_t s_vals[GSX_SORT_TILE];
-    __shared__ uint32_t s_whist[GSX_SORT_NT / 64][GSX_RADIX];
-    __shared__ uint32_t s_binbase[GSX_RADIX];
-    __shared__ uint32_t s_gofs[GSX_RADIX];
-    __shared__ uint32_t s_tmp[GSX_SORT_NT / 64];
-    __shared__ uint32_t s_tile;
-    if (plan->skip[pass]) return;
-    const uint32_t m = plan->m;
-    if (threadIdx.x == 0) s_tile = atomicAdd(&zero->tile_ctr[pass], 1u);
-    for (uint32_t t = threadIdx.x; t < (GSX_SORT_NT / 64) * GSX_RADIX; t += GSX_SORT_NT) (&s_whist[0][0])[t] = 0;
-    __syncthreads();
-    const uint32_t tile = s_tile;
-    if (static_cast<uint64_t>(tile) * GSX_SORT_TILE >= m) return;
-    const uint32_t src = plan->src[pass];
-    const uint32_t* kin = src ? k1 : k0;
-    uint32_t* kout = src ? k0 : k1;
-    const uint32_t* vin = (pass == 0) ? sel : (src ? v1 : v0);
-    uint32_t* vout = src ? v0 : v1;
-    gsx_onesweep_tile<uint32_t, GSX_SORT_NT, GSX_SORT_IPT, IOTA>(kin, vin, kout, vout, m, 8u * pass, tile, status,
-                                                                 plan->gbase[pass], spin_flag, s_keys, s_vals, s_whist,
-                                                                 s_binbase, s_gofs, s_tmp);
+int gsx_launch_aabb(gsx_ctx* c) {
+    const int init[6] = {0x7FFFFFFF, 0x7FFFFFFF, 0x7FFFFFFF, (int)0x80000000, (int)0x80000000, (int)0x80000000};
+    GSX_HIP(c, hipMemcpyAsync(c->aabb_dev, init, sizeof init, hipMemcpyHostToDevice, c->stream));
+    if (c->n) hipLaunchKernelGGL(k_aabb, dim3(min(gsx_div_up(c->n, 256 * 8), 2048u)), dim3(256), 0, c->stream, c->pos4, c->n,
+                                 reinterpret_cast<int*>(c->aabb_dev));
+    int out[6];
+    GSX_HIP(c, hipMemcpyAsync(out, c->aabb_dev, sizeof out, hipMemcpyDeviceToHost, c->stream));
+    GSX_HIP(c, hipStreamSynchronize(c->stream));
+    c->aabb_valid = c->n > 0;
+    for (int k = 0; k < 3; ++k) {
+        if (out[k] > out[3 + k]) { c->aabb_valid = false; break; }
+        const int a = out[k] >= 0 ? out[k] : out[k] ^ 0x7FFFFFFF, b = out[3 + k] >= 0 ? out[3 + k] : out[3 + k] ^ 0x7FFFFFFF;
+        memcpy(&c->aabb_min[k], &a, 4);
+        memcpy(&c->aabb_max[k], &b, 4);
+        if (!std::isfinite(c->aabb_min[k]) || !std::isfinite(c->aabb_max[k])) c->aabb_valid = false;
+    }
+    return GSX_OK;
 }
 
-static inline uint64_t sort_status_words(uint64_t cap) { return static_cast<uint64_t>(gsx_div_up(cap, GSX_SORT_TILE)) * GSX_RADIX; }
+static uint32_t host_key(float d) {
+    uint32_t b;
+    memcpy(&b, &d, 4);
+    return (~b) & 0x7FFFFFFFu;
+}
+
+// Conservative key range of the frame from the scene bounds: every distance lies in
+// [dist(cam, box), dist(cam, farthest corner)], widened by 1e-5 relative.
+static void key_bounds(const gsx_ctx* c, uint32_t* key_lo, uint32_t* key_span) {
+    *key_lo = 0;
+    *key_span = 0x7FFFFFFFu;
+    if (!c->aabb_valid) return;
+    double near2 = 0.0, far2 = 0.0;
+    for (int k = 0; k < 3; ++k) {
+        const double cam = c->cam[k], lo = c->aabb_min[k], hi = c->aabb_max[k];
+        if (!std::isfinite(cam)) return;
+        const double dn = cam < lo ? lo - cam : (cam > hi ? cam - hi : 0.0);
+        const double df = std::fmax(std::fabs(cam - lo), std::fabs(cam - hi));
+        near2 += dn * dn;
+        far2 += df * df;
+    }
+    const double dmin = std::sqrt(near2) * (1.0 - 1e-5), dmax = std::sqrt(far2) * (1.0 + 1e-5) + 1e-30;
+    if (!(dmax < 3.0e38)) return;
+    const uint32_t lo = host_key(static_cast<float>(dmax)), hi = host_key(static_cast<float>(dmin));
+    if (hi < lo) return;
+    *key_lo = lo;
+    *key_span = hi - lo;
+}
+
+template <typename KeyT, int NT, int IPT>
+static void launch_pass(gsx_ctx* c, hipStream_t st, uint32_t g, const KeyT* kin, const uint32_t* vin, KeyT* kout, uint32_t* vout,
+                        const uint32_t* count_ptr, uint32_t shift, uint32_t bits, uint32_t* ws, bool need_hist, bool iota) {
+    uint32_t* cnt = ws;
+    uint32_t* totals = ws + static_cast<uint64_t>(GSX_RADIX_MAX_DIGITS) * g;
+    if (need_hist)
+        hipLaunchKernelGGL((k_radix_hist<KeyT, NT, IPT>), dim3(g), dim3(NT), 0, st, kin, count_ptr, shift, bits, cnt);
+    hipLaunchKernelGGL((k_radix_scan<0>), dim3(1u << bits), dim3(256), 0, st, cnt, g, totals);
+    if (iota)
+        hipLaunchKernelGGL((k_radix_scatter<KeyT, NT, IPT, true>), dim3(g), dim3(NT), 0, st, kin, vin, kout, vout, count_ptr, shift,
+                           bits, cnt, totals);
+    else
+        hipLaunchKernelGGL((k_radix_scatter<KeyT, NT, IPT, false>), dim3(g), dim3(NT), 0, st, kin, vin, kout, vout, count_ptr, shift,
+                           bits, cnt, totals);
+    (void)c;
+}
 
 int gsx_launch_sort(gsx_ctx* c) {
     const uint32_t cap = c->m_cap;
-    const uint32_t n_tiles = gsx_div_up(cap, GSX_SORT_TILE);
-    const uint64_t zero_bytes = sizeof(GsxSortZero) + static_cast<uint64_t>(GSX_PASSES) * sort_status_words(cap) * 4;
-    if (zero_bytes > c->sort_zero_bytes) { c->err = "sort workspace too small"; return GSX_E_INTERNAL; }
+    const uint32_t g = gsx_radix_blocks(cap, GSX_SORT_TILE);
+    if (gsx_radix_workspace_words(g) > c->sort_ws_words) { c->err = "sort workspace too small"; return GSX_E_INTERNAL; }
+    uint32_t key_lo, key_span;
+    key_bounds(c, &key_lo, &key_span);
+    uint32_t total_bits = 0;
+    while (total_bits < 32 && (static_cast<uint64_t>(key_span) >> total_bits) != 0) ++total_bits;
+    const GsxRadixPlan plan = gsx_radix_plan(total_bits);
     if (c->profiling) GSX_HIP(c, hipEventRecord(c->ev[EV_KEY0], c->stream));
-    GSX_HIP(c, hipMemsetAsync(c->sort_zero, 0, zero_bytes, c->stream));
-    if (cap > 0) {
-        const uint32_t blocks = min(gsx_div_up(cap, 256 * 4), 2048u);
-        if (c->sel_iota)
-            hipLaunchKernelGGL(k_keygen_hist<true>, dim3(blocks), dim3(256), 0, c->stream, c->pos4, nullptr, c->m_dev,
-                               c->cam[0], c->cam[1], c->cam[2], c->keys[0], &c->sort_zero->ghist[0][0]);
-        else
-            hipLaunchKernelGGL(k_keygen_hist<false>, dim3(blocks), dim3(256), 0, c->stream, c->pos4, c->sel_idx, c->m_dev,
-                               c->cam[0], c->cam[1], c->cam[2], c->keys[0], &c->sort_zero->ghist[0][0]);
-    }
-    hipLaunchKernelGGL(k_sort_plan, dim3(1), dim3(256), 0, c->stream, &c->sort_zero->ghist[0][0], c->m_dev, c->plan);
+    if (c->sel_iota)
+        hipLaunchKernelGGL(k_keygen_hist0<true>, dim3(g), dim3(GSX_SORT_NT), 0, c->stream, c->pos4, nullptr, c->m_dev, c->cam[0],
+                           c->cam[1], c->cam[2], key_lo, key_span, plan.shift[0], plan.bits[0], c->keys[0], c->sort_ws, c->flags);
+    else
+        hipLaunchKernelGGL(k_keygen_hist0<false>, dim3(g), dim3(GSX_SORT_NT), 0, c->stream, c->pos4, c->sel_idx, c->m_dev, c->cam[0],
+                           c->cam[1], c->cam[2], key_lo, key_span, plan.shift[0], plan.bits[0], c->keys[0], c->sort_ws, c->flags);
     if (c->profiling) GSX_HIP(c, hipEventRecord(c->ev[EV_KEY1], c->stream));
-    uint32_t* status0 = reinterpret_cast<uint32_t*>(c->sort_zero + 1);
-    for (int p = 0; p < GSX_PASSES && n_tiles > 0; ++p) {
-        uint32_t* status = status0 + static_cast<uint64_t>(p) * sort_status_words(cap);
-        if (p == 0 && c->sel_iota)
-            hipLaunchKernelGGL(k_sort_pass<true>, dim3(n_tiles), dim3(GSX_SORT_NT), 0, c->stream, c->keys[0], c->keys[1],
-                               c->vals[0], c->vals[1], nullptr, p, c->plan, c->sort_zero, status, &c->flags->spin_expired);
-        else
-            hipLaunchKernelGGL(k_sort_pass<false>, dim3(n_tiles), dim3(GSX_SORT_NT), 0, c->stream, c->keys[0], c->keys[1],
-                               c->vals[0], c->vals[1], c->sel_idx, p, c->plan, c->sort_zero, status, &c->flags->spin_expired);
+    uint32_t cur = 0;
+    for (int p = 0; p < plan.n_passes; ++p) {
+        const bool first = p == 0;
+        launch_pass<uint32_t, GSX_SORT_NT, GSX_SORT_IPT>(c, c->stream, g, c->keys[cur], first ? c->sel_idx : c->vals[cur], c->keys[cur ^ 1],
+                                                          c->vals[cur ^ 1], c->m_dev, plan.shift[p], plan.bits[p], c->sort_ws,
+                                                          /*need_hist=*/!first, /*iota=*/first && c->sel_iota);
+        cur ^= 1;
     }
     if (c->profiling) GSX_HIP(c, hipEventRecord(c->ev[EV_SORT1], c->stream));
     GSX_HIP(c, hipGetLastError());
     c->sorted_valid = true;
+    c->sorted_buf = cur;
+    c->sort_passes = static_cast<uint32_t>(plan.n_passes);
     return GSX_OK;
 }
 
@@ -223,6 +249,4 @@ int gsx_launch_keys_only(gsx_ctx* c, float* dist_dev) {
     return GSX_OK;
 }
 
-uint64_t gsx_sort_workspace_bytes(uint64_t cap) {
-    return sizeof(GsxSortZero) + static_cast<uint64_t>(GSX_PASSES) * sort_status_words(cap) * 4;
-}
+uint64_t gsx_sort_workspace_words(uint64_t cap) { return gsx_radix_workspace_words(gsx_radix_blocks(cap, GSX_SORT_TILE)); }
