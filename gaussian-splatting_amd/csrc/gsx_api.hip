@@ -7,6 +7,8 @@
 
 uint64_t gsx_sort_workspace_words(uint64_t cap);
 int gsx_launch_aabb(gsx_ctx* c);
+uint32_t gsx_sort_slots(int cus);
+uint32_t gsx_pair_slots(int cus);
 
 namespace {
 
@@ -82,6 +84,12 @@ int gsx_create(int device, gsx_ctx** out) {
     auto fail = [&](int rc) { gsx_destroy(c); return rc; };
     if (hipSetDevice(device) != hipSuccess) return fail(GSX_E_HIP);
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return fail(GSX_E_HIP);
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus < 1) cus = 256;
+        c->sort_slots = gsx_sort_slots(cus);
+        c->pair_slots = gsx_pair_slots(cus);
+    }
     for (int i = 0; i < EV_COUNT; ++i)
         if (hipEventCreate(&c->ev[i]) != hipSuccess) return fail(GSX_E_HIP);
     if (hipMalloc(reinterpret_cast<void**>(&c->m_dev), 16) != hipSuccess) return fail(GSX_E_NOMEM);

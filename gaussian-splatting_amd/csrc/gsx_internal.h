@@ -15,7 +15,7 @@
 #define GSX_SORT_NT 256
 #endif
 #ifndef GSX_SORT_IPT
-#define GSX_SORT_IPT 16
+#define GSX_SORT_IPT 12
 #endif
 #define GSX_SORT_TILE (GSX_SORT_NT * GSX_SORT_IPT)
 #define GSX_PAIR_NT 256
@@ -88,6 +88,7 @@ struct gsx_ctx {
     bool sorted_valid = false;
     uint32_t sorted_buf = 0;           // vals[sorted_buf] holds the permutation
     uint32_t sort_passes = 0;
+    uint32_t sort_slots = 1024, pair_slots = 1024;   // resident workgroups of the scatter kernels (CUs x blocks/CU)
     float cam[3] = {0, 0, 0};
     float aabb_min[3] = {0, 0, 0}, aabb_max[3] = {0, 0, 0};  // of the uploaded positions
     bool aabb_valid = false;

@@ -2,6 +2,7 @@
 // as three kernels per digit pass:
 //
 //   H  k_radix_hist     every block counts the digits of ITS contiguous key range
+//                       (replicated LDS atomics, 16-byte loads)
 //   S  k_radix_scan     one block per digit: exclusive scan of that digit's counts
 //                       over blocks (+ the digit's total)
 //   X  k_radix_scatter  every block re-reads its range tile by tile, ranks the keys
@@ -76,60 +77,83 @@ __device__ __forceinline__ uint64_t gsx_match_digit(uint32_t d, uint32_t bits) {
     return peers;
 }
 
-// Tiles [first, last) of block `b` when n_tiles tiles are dealt to `g` blocks in contiguous ranges.
-__device__ __forceinline__ void gsx_block_tiles(uint32_t n_tiles, uint32_t g, uint32_t b, uint32_t& first, uint32_t& last) {
-    const uint32_t per = (n_tiles + g - 1) / g;
-    first = min(b * per, n_tiles);
-    last = min(first + per, n_tiles);
+// Logical range index of this workgroup.  Workgroups are dealt round-robin over the 8
+// XCDs (blockIdx % 8 labels the XCD group), each with a private L2; giving every XCD
+// group one contiguous eighth of the key space makes neighbouring ranges -- whose
+// output runs are adjacent for every digit -- share an L2, so partial-line writes
+// combine before they leave the chip.  Bijective for any grid size.  Speed only:
+// correctness never depends on placement.
+__device__ __forceinline__ uint32_t gsx_logical_block() {
+#ifdef GSX_NO_XCD_REMAP
+    return blockIdx.x;
+#else
+    const uint32_t g = gridDim.x, orig = blockIdx.x;
+    const uint32_t q = g / 8, r = g % 8, xcd = orig % 8;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + orig / 8;
+#endif
+}
+
+// Keys [begin, end) owned by logical block `b` when `count` keys are dealt to `g` blocks in
+// equal contiguous ranges (range length rounded up to 256 keys so every range starts on
+// a 1-KiB boundary).  The grid is sized to the machine (one round of resident
+// workgroups), so all blocks carry the same load and there is no tail round.
+__device__ __forceinline__ void gsx_block_range(uint32_t count, uint32_t g, uint32_t b, uint32_t& begin, uint32_t& end) {
+    const uint64_t per = ((static_cast<uint64_t>(count) + g - 1) / g + 255) / 256 * 256;
+    const uint64_t lo = per * b;
+    begin = static_cast<uint32_t>(lo < count ? lo : count);
+    end = static_cast<uint32_t>(lo + per < count ? lo + per : count);
+}
+
+// Contention-tolerant LDS digit histogram: GSX_HREP interleaved copies, lane l uses copy
+// l % GSX_HREP, so even a constant digit is only an 8-way conflict.
+#define GSX_HREP 8
+__device__ __forceinline__ void gsx_hist_zero(uint32_t* s_hist, int nt) {
+    for (uint32_t t = threadIdx.x; t < GSX_RADIX_MAX_DIGITS * GSX_HREP; t += nt) s_hist[t] = 0;
+    __syncthreads();
+}
+__device__ __forceinline__ void gsx_hist_add(uint32_t* s_hist, uint32_t d) {
+    atomicAdd(&s_hist[d * GSX_HREP + (threadIdx.x & (GSX_HREP - 1))], 1u);
+}
+__device__ __forceinline__ void gsx_hist_store(const uint32_t* s_hist, uint32_t nd, int nt, uint32_t* __restrict__ cnt) {
+    __syncthreads();
+    const uint32_t col = gsx_logical_block();
+    for (uint32_t d = threadIdx.x; d < nd; d += nt) {
+        uint32_t acc = 0;
+#pragma unroll
+        for (int r = 0; r < GSX_HREP; ++r) acc += s_hist[d * GSX_HREP + r];
+        cnt[static_cast<uint64_t>(d) * gridDim.x + col] = acc;
+    }
 }
 
 // ---- H: digit counts of each block's range -> cnt[d * G + b] -----------------
-// Also usable as a device function by producers that already hold the keys
-// (the depth-key kernel counts pass 0 while it writes the keys).
-template <int NT>
-__device__ __forceinline__ void gsx_hist_flush(uint32_t (*s_whist)[GSX_RADIX_MAX_DIGITS], uint32_t nd, uint32_t* __restrict__ cnt) {
-    __syncthreads();
-    for (uint32_t d = threadIdx.x; d < nd; d += NT) {
-        uint32_t acc = 0;
-#pragma unroll
-        for (int w = 0; w < NT / 64; ++w) acc += s_whist[w][d];
-        cnt[static_cast<uint64_t>(d) * gridDim.x + blockIdx.x] = acc;
-    }
-}
-
-template <typename KeyT, int NT, int IPT>
+template <typename KeyT, int NT>
 __global__ __launch_bounds__(NT) void k_radix_hist(const KeyT* __restrict__ keys, const uint32_t* __restrict__ count_ptr,
                                                    uint32_t shift, uint32_t bits, uint32_t* __restrict__ cnt) {
-    __shared__ uint32_t s_whist[NT / 64][GSX_RADIX_MAX_DIGITS];
-    constexpr int TILE = NT * IPT;
+    __shared__ uint32_t s_hist[GSX_RADIX_MAX_DIGITS * GSX_HREP];
     const uint32_t nd = 1u << bits, mask = nd - 1u;
-    const uint32_t count = *count_ptr;
-    for (uint32_t t = threadIdx.x; t < (NT / 64) * GSX_RADIX_MAX_DIGITS; t += NT) (&s_whist[0][0])[t] = 0;
-    __syncthreads();
-    uint32_t first, last;
-    gsx_block_tiles((count + TILE - 1) / TILE, gridDim.x, blockIdx.x, first, last);
-    uint32_t* wh = s_whist[threadIdx.x >> 6];
-    const uint64_t begin = static_cast<uint64_t>(first) * TILE, end = min(static_cast<uint64_t>(last) * TILE, static_cast<uint64_t>(count));
-    // whole waves stay in the loop together (begin is a multiple of 64*...), tail lanes are masked
-    for (uint64_t base = begin; base < end; base += static_cast<uint64_t>(NT) * 4) {
-        KeyT k[4];
-        bool ok[4];
+    gsx_hist_zero(s_hist, NT);
+    uint32_t begin, end;
+    gsx_block_range(*count_ptr, gridDim.x, gsx_logical_block(), begin, end);
+    constexpr int VEC = 16 / sizeof(KeyT);          // keys per 16-byte load; ranges start 16-byte aligned
+    using VecT = uint4;
+    const uint32_t n_vec = (end - begin) / VEC;
+    const VecT* kv = reinterpret_cast<const VecT*>(keys + begin);
+    for (uint32_t i = threadIdx.x; i < n_vec; i += NT) {
+        const VecT v = kv[i];
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const uint64_t g = base + static_cast<uint64_t>(j) * NT + threadIdx.x;
-            ok[j] = g < end;
-            k[j] = ok[j] ? keys[g] : static_cast<KeyT>(0);
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            // padding lanes take digit `nd` .. never: give them their own pseudo digit by clearing them from the peers
-            const uint32_t d = (static_cast<uint32_t>(k[j]) >> shift) & mask;
-            const uint64_t live = __builtin_amdgcn_ballot_w64(ok[j]);
-            const uint64_t peers = gsx_match_digit(d, bits) & live;
-            if (ok[j] && gsx_mbcnt(peers) == 0) atomicAdd(&wh[d], static_cast<uint32_t>(__popcll(peers)));
+            if (sizeof(KeyT) == 4) {
+                gsx_hist_add(s_hist, (w[j] >> shift) & mask);
+            } else {
+                gsx_hist_add(s_hist, ((w[j] & 0xFFFFu) >> shift) & mask);
+                gsx_hist_add(s_hist, ((w[j] >> 16) >> shift) & mask);
+            }
         }
     }
-    gsx_hist_flush<NT>(s_whist, nd, cnt);
+    for (uint32_t g = begin + n_vec * VEC + threadIdx.x; g < end; g += NT)
+        gsx_hist_add(s_hist, (static_cast<uint32_t>(keys[g]) >> shift) & mask);
+    gsx_hist_store(s_hist, nd, NT, cnt);
 }
 
 // ---- S: per digit, exclusive scan over blocks (in place) + digit total --------
@@ -173,9 +197,9 @@ __global__ __launch_bounds__(NT) void k_radix_scatter(const KeyT* __restrict__ k
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t nd = 1u << bits, mask = nd - 1u;
     const uint32_t count = *count_ptr;
-    uint32_t first, last;
-    gsx_block_tiles((count + TILE - 1) / TILE, gridDim.x, blockIdx.x, first, last);
-    if (first >= last) return;
+    uint32_t rbegin, rend;
+    gsx_block_range(count, gridDim.x, gsx_logical_block(), rbegin, rend);
+    if (rbegin >= rend) return;
 
     // running offsets: exclusive scan of the digit totals + this block's scanned count.
     // Thread t owns the PER consecutive digits t*PER .. t*PER+PER-1.
@@ -193,14 +217,13 @@ __global__ __launch_bounds__(NT) void k_radix_scatter(const KeyT* __restrict__ k
 #pragma unroll
         for (int j = 0; j < PER; ++j) {
             const uint32_t d = tid * PER + j;
-            if (d < nd) s_run[d] = run + cnt_scanned[static_cast<uint64_t>(d) * gridDim.x + blockIdx.x];
+            if (d < nd) s_run[d] = run + cnt_scanned[static_cast<uint64_t>(d) * gridDim.x + gsx_logical_block()];
             run += tot[j];
         }
     }
     __syncthreads();
 
-    for (uint32_t tile = first; tile < last; ++tile) {
-        const uint32_t tile_base = tile * TILE;
+    for (uint32_t tile_base = rbegin; tile_base < rend; tile_base += TILE) {
         const uint32_t wave_base = tile_base + wave * (64 * IPT);
         // ---- load keys and values together (wave-striped: item i of lane l = wave_base + i*64 + l) ----
         KeyT key[IPT];
@@ -208,8 +231,8 @@ __global__ __launch_bounds__(NT) void k_radix_scatter(const KeyT* __restrict__ k
 #pragma unroll
         for (int i = 0; i < IPT; ++i) {
             const uint32_t g = wave_base + i * 64 + lane;
-            key[i] = (g < count) ? keys_in[g] : static_cast<KeyT>(~static_cast<KeyT>(0));
-            val[i] = IOTA_VALS ? g : ((g < count) ? vals_in[g] : 0u);
+            key[i] = (g < rend) ? keys_in[g] : static_cast<KeyT>(~static_cast<KeyT>(0));
+            val[i] = IOTA_VALS ? g : ((g < rend) ? vals_in[g] : 0u);
         }
         for (uint32_t t = tid; t < NW * GSX_RADIX_MAX_DIGITS; t += NT) (&s_whist[0][0])[t] = 0;
         __syncthreads();   // also: previous tile's write-out has finished reading s_keys/s_vals/s_gofs
@@ -277,7 +300,7 @@ __global__ __launch_bounds__(NT) void k_radix_scatter(const KeyT* __restrict__ k
         __syncthreads();
 
         // ---- write-out: consecutive LDS slots of one digit are consecutive in HBM ----
-        const uint32_t valid = (count - tile_base < static_cast<uint32_t>(TILE)) ? (count - tile_base) : TILE;
+        const uint32_t valid = (rend - tile_base < static_cast<uint32_t>(TILE)) ? (rend - tile_base) : TILE;
 #pragma unroll
         for (int i = 0; i < IPT; ++i) {
             const uint32_t p = i * NT + tid;
@@ -315,9 +338,14 @@ static inline GsxRadixPlan gsx_radix_plan(uint32_t total_bits) {
     return p;
 }
 
-static inline uint32_t gsx_radix_blocks(uint64_t cap, uint32_t tile) {
-    const uint64_t t = (cap + tile - 1) / tile;
-    return static_cast<uint32_t>(t < 1 ? 1 : (t > GSX_RADIX_MAX_BLOCKS ? GSX_RADIX_MAX_BLOCKS : t));
+// Grid of a sort of up to `cap` keys: one round of resident workgroups (`slots`), but never
+// more blocks than tiles.
+static inline uint32_t gsx_radix_blocks(uint64_t cap, uint32_t tile, uint32_t slots) {
+    uint64_t t = (cap + tile - 1) / tile;
+    if (t < 1) t = 1;
+    if (t > slots) t = slots;
+    if (t > GSX_RADIX_MAX_BLOCKS) t = GSX_RADIX_MAX_BLOCKS;
+    return static_cast<uint32_t>(t);
 }
 // bytes of the count matrix + totals for one sort of up to `cap` keys
 static inline uint64_t gsx_radix_workspace_words(uint32_t blocks) {

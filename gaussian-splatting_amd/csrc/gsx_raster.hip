@@ -438,14 +438,14 @@ int gsx_launch_render(gsx_ctx* c, const gsx_uniforms* u, uint32_t w, uint32_t h,
         uint32_t tile_bits = 1;
         while ((1u << tile_bits) < n_tiles) ++tile_bits;
         const GsxRadixPlan plan = gsx_radix_plan(tile_bits);
-        const uint32_t g = gsx_radix_blocks(total_pairs, GSX_PAIR_TILE);
+        const uint32_t g = gsx_radix_blocks(total_pairs, GSX_PAIR_TILE, c->pair_slots);
         if ((rc = ensure(c, &c->pair_ws, &c->pair_ws_words, gsx_radix_workspace_words(g))) != GSX_OK) return rc;
         GSX_HIP(c, hipMemcpyAsync(c->pair_total_dev, c->host_word, 4, hipMemcpyHostToDevice, c->stream));  // (already there; keeps count_ptr explicit)
         uint32_t* cnt = c->pair_ws;
         uint32_t* totals = cnt + static_cast<uint64_t>(GSX_RADIX_MAX_DIGITS) * g;
         int cur = 0;
         for (int p = 0; p < plan.n_passes; ++p) {
-            hipLaunchKernelGGL((k_radix_hist<uint16_t, GSX_PAIR_NT, GSX_PAIR_IPT>), dim3(g), dim3(GSX_PAIR_NT), 0, c->stream,
+            hipLaunchKernelGGL((k_radix_hist<uint16_t, GSX_PAIR_NT>), dim3(g), dim3(GSX_PAIR_NT), 0, c->stream,
                                c->pair_key[cur], c->pair_total_dev, plan.shift[p], plan.bits[p], cnt);
             hipLaunchKernelGGL((k_radix_scan<0>), dim3(1u << plan.bits[p]), dim3(256), 0, c->stream, cnt, g, totals);
             hipLaunchKernelGGL((k_radix_scatter<uint16_t, GSX_PAIR_NT, GSX_PAIR_IPT, false>), dim3(g), dim3(GSX_PAIR_NT), 0, c->stream,
@@ -477,4 +477,10 @@ int gsx_launch_render(gsx_ctx* c, const gsx_uniforms* u, uint32_t w, uint32_t h,
     if (c->profiling) GSX_HIP(c, hipEventRecord(c->ev[EV_RAST1], c->stream));
     GSX_HIP(c, hipGetLastError());
     return GSX_OK;
+}
+
+uint32_t gsx_pair_slots(int cus) {
+    int per = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, k_radix_scatter<uint16_t, GSX_PAIR_NT, GSX_PAIR_IPT, false>, GSX_PAIR_NT, 0) != hipSuccess || per < 1) per = 2;
+    return static_cast<uint32_t>(cus) * static_cast<uint32_t>(per);
 }

@@ -67,46 +67,36 @@ __global__ __launch_bounds__(GSX_SORT_NT) void k_keygen_hist0(const float4* __re
                                                               uint32_t key_lo, uint32_t key_span, uint32_t shift, uint32_t bits,
                                                               uint32_t* __restrict__ keys, uint32_t* __restrict__ cnt,
                                                               GsxDevFlags* __restrict__ flags) {
-    __shared__ uint32_t s_whist[GSX_SORT_NT / 64][GSX_RADIX_MAX_DIGITS];
+    __shared__ uint32_t s_hist[GSX_RADIX_MAX_DIGITS * GSX_HREP];
     const uint32_t nd = 1u << bits, mask = nd - 1u;
-    const uint32_t m = *m_ptr;
-    for (uint32_t t = threadIdx.x; t < (GSX_SORT_NT / 64) * GSX_RADIX_MAX_DIGITS; t += GSX_SORT_NT) (&s_whist[0][0])[t] = 0;
-    __syncthreads();
-    uint32_t first, last;
-    gsx_block_tiles((m + GSX_SORT_TILE - 1) / GSX_SORT_TILE, gridDim.x, blockIdx.x, first, last);
-    uint32_t* wh = s_whist[threadIdx.x >> 6];
-    const uint64_t begin = static_cast<uint64_t>(first) * GSX_SORT_TILE;
-    const uint64_t end = min(static_cast<uint64_t>(last) * GSX_SORT_TILE, static_cast<uint64_t>(m));
+    gsx_hist_zero(s_hist, GSX_SORT_NT);
+    uint32_t begin, end;
+    gsx_block_range(*m_ptr, gridDim.x, gsx_logical_block(), begin, end);
     constexpr int UNROLL = 4;
-    for (uint64_t base = begin; base < end; base += static_cast<uint64_t>(GSX_SORT_NT) * UNROLL) {
+    for (uint32_t base = begin + threadIdx.x; base < end; base += GSX_SORT_NT * UNROLL) {
         float4 p[UNROLL];
         bool ok[UNROLL];
 #pragma unroll
         for (int j = 0; j < UNROLL; ++j) {
-            const uint64_t k = base + static_cast<uint64_t>(j) * GSX_SORT_NT + threadIdx.x;
+            const uint32_t k = base + j * GSX_SORT_NT;
             ok[j] = k < end;
-            if (ok[j]) p[j] = pos4[IOTA ? static_cast<uint32_t>(k) : sel[k]];
+            if (ok[j]) p[j] = pos4[IOTA ? k : sel[k]];
         }
 #pragma unroll
         for (int j = 0; j < UNROLL; ++j) {
-            const uint64_t k = base + static_cast<uint64_t>(j) * GSX_SORT_NT + threadIdx.x;
-            uint32_t rel = 0;
-            if (ok[j]) {
-                const uint32_t key = gsx_key_from_distance(gsx_distance(p[j], cx, cy, cz));
-                rel = key - key_lo;
-                if (key < key_lo || rel > key_span) {   // outside the bound: NaN/inf position
-                    atomicOr(&flags->key_bound, 1u);
-                    rel = (key < key_lo) ? 0u : key_span;
-                }
-                keys[k] = rel;
+            if (!ok[j]) continue;
+            const uint32_t k = base + j * GSX_SORT_NT;
+            const uint32_t key = gsx_key_from_distance(gsx_distance(p[j], cx, cy, cz));
+            uint32_t rel = key - key_lo;
+            if (key < key_lo || rel > key_span) {   // outside the bound: NaN/inf position
+                atomicOr(&flags->key_bound, 1u);
+                rel = (key < key_lo) ? 0u : key_span;
             }
-            const uint32_t d = (rel >> shift) & mask;
-            const uint64_t live = __builtin_amdgcn_ballot_w64(ok[j]);
-            const uint64_t peers = gsx_match_digit(d, bits) & live;
-            if (ok[j] && gsx_mbcnt(peers) == 0) atomicAdd(&wh[d], static_cast<uint32_t>(__popcll(peers)));
+            keys[k] = rel;
+            gsx_hist_add(s_hist, (rel >> shift) & mask);
         }
     }
-    gsx_hist_flush<GSX_SORT_NT>(s_whist, nd, cnt);
+    gsx_hist_store(s_hist, nd, GSX_SORT_NT, cnt);
 }
 
 // Distances only (parity aid for gsx_get_keys).
@@ -193,7 +183,7 @@ static void launch_pass(gsx_ctx* c, hipStream_t st, uint32_t g, const KeyT* kin,
     uint32_t* cnt = ws;
     uint32_t* totals = ws + static_cast<uint64_t>(GSX_RADIX_MAX_DIGITS) * g;
     if (need_hist)
-        hipLaunchKernelGGL((k_radix_hist<KeyT, NT, IPT>), dim3(g), dim3(NT), 0, st, kin, count_ptr, shift, bits, cnt);
+        hipLaunchKernelGGL((k_radix_hist<KeyT, NT>), dim3(g), dim3(NT), 0, st, kin, count_ptr, shift, bits, cnt);
     hipLaunchKernelGGL((k_radix_scan<0>), dim3(1u << bits), dim3(256), 0, st, cnt, g, totals);
     if (iota)
         hipLaunchKernelGGL((k_radix_scatter<KeyT, NT, IPT, true>), dim3(g), dim3(NT), 0, st, kin, vin, kout, vout, count_ptr, shift,
@@ -206,7 +196,7 @@ static void launch_pass(gsx_ctx* c, hipStream_t st, uint32_t g, const KeyT* kin,
 
 int gsx_launch_sort(gsx_ctx* c) {
     const uint32_t cap = c->m_cap;
-    const uint32_t g = gsx_radix_blocks(cap, GSX_SORT_TILE);
+    const uint32_t g = gsx_radix_blocks(cap, GSX_SORT_TILE, c->sort_slots);
     if (gsx_radix_workspace_words(g) > c->sort_ws_words) { c->err = "sort workspace too small"; return GSX_E_INTERNAL; }
     uint32_t key_lo, key_span;
     key_bounds(c, &key_lo, &key_span);
@@ -249,4 +239,11 @@ int gsx_launch_keys_only(gsx_ctx* c, float* dist_dev) {
     return GSX_OK;
 }
 
-uint64_t gsx_sort_workspace_words(uint64_t cap) { return gsx_radix_workspace_words(gsx_radix_blocks(cap, GSX_SORT_TILE)); }
+uint64_t gsx_sort_workspace_words(uint64_t cap) { return gsx_radix_workspace_words(gsx_radix_blocks(cap, GSX_SORT_TILE, GSX_RADIX_MAX_BLOCKS)); }
+
+// Resident workgroups of the depth sort's scatter kernel on this device (CUs x blocks per CU).
+uint32_t gsx_sort_slots(int cus) {
+    int per = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, k_radix_scatter<uint32_t, GSX_SORT_NT, GSX_SORT_IPT, false>, GSX_SORT_NT, 0) != hipSuccess || per < 1) per = 2;
+    return static_cast<uint32_t>(cus) * static_cast<uint32_t>(per);
+}
