@@ -14,7 +14,7 @@ gathered to rank 0 with RCCL inside the timed region.
 
 Prints ONE JSON line on rank 0.  `value` = splats sorted (and drawn) per second
 over whole frames, aggregated over ranks; `fps_1080p` and the sort-only rate are
-reported next to it.  `roofline` describes the radix-pass kernel (k_sort_pass);
+reported next to it.  `roofline` describes the radix scatter kernel (k_radix_scatter);
 `cpu_baseline` times the CPU port of the reference's sortSplats on rank 0.
 """
 import argparse
@@ -29,8 +29,16 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-SORT_PASS_BYTES_PER_SPLAT = 16  # one radix pass: read key+index (8 B), write key+index (8 B)
-SORT_TOTAL_BYTES_PER_SPLAT = 16 + 4 + 4 * 16  # keygen 16 B read + 4 B key write, 4 passes (pass 0 regenerates the index: 12 B)
+SCATTER_BYTES_PER_SPLAT = 16    # one k_radix_scatter launch: read key+index (8 B), write key+index (8 B)
+KEYGEN_BYTES_PER_SPLAT = 20     # float4 position read + u32 key write (pass-0 digit count fused, no extra bytes)
+COUNT_BYTES_PER_SPLAT = 4       # k_radix_hist of passes >= 1: key read
+
+
+def sort_bytes_per_splat(passes):
+    """Algorithmic HBM bytes per splat of keys + sort: SURVEY 8(d) counts 92 B for
+    a 4-pass onesweep; this design runs `passes` scatter passes plus a 4-B count read for every pass but
+    the first."""
+    return KEYGEN_BYTES_PER_SPLAT + passes * SCATTER_BYTES_PER_SPLAT + max(passes - 1, 0) * COUNT_BYTES_PER_SPLAT
 
 
 def load_pkg():
@@ -87,7 +95,7 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--scene", default="clustered")
-    ap.add_argument("--cpu-frames", type=int, default=5, help="frames of the CPU baseline (0 = skip)")
+    ap.add_argument("--cpu-frames", type=int, default=20, help="frames of the CPU baseline (0 = skip)")
     ap.add_argument("--no-gather", action="store_true")
     a = ap.parse_args()
 
@@ -110,7 +118,8 @@ def main():
     W, H = a.width, a.height
     views = orbit_views(pkg, 64, W, H)
     # view-batch sharding: rank r owns views r, r+world, ... (independent units, no data-path collective)
-    my_views = views[rank::world] if world > 1 else views[:1]
+    mg = importlib.import_module("gaussian_splatting_amd.multigpu")
+    my_views = [views[i] for i in mg.shard_views(len(views), rank, world)] if world > 1 else views[:1]
 
     g = pkg.Gsx(local_rank)
     g.upload(splats)
@@ -131,12 +140,7 @@ def main():
         g.sync()
         ptr, _, _ = g.framebuffer_dev()
         fb = torch.as_tensor(DevArray(ptr, fb_bytes), device=torch.device("cuda", local_rank))
-        if rank == 0:
-            if gather_buf is None:
-                gather_buf = [torch.empty(fb_bytes, dtype=torch.uint8, device=fb.device) for _ in range(world)]
-            dist.gather(fb, gather_buf, dst=0)
-        else:
-            dist.gather(fb, None, dst=0)
+        gather_buf = mg.gather_to_rank0(dist, fb, rank, world, gather_buf)
 
     def fence():
         if dist is not None:
@@ -169,10 +173,10 @@ def main():
         K = a.steps
         n = a.splats
         passes = acc["sort_passes"] / K
-        sort_ms = acc["sort_ms"] / K
-        pass_ms = sort_ms / max(passes, 1.0)
-        achieved = SORT_PASS_BYTES_PER_SPLAT * n / (pass_ms * 1e-3) / 1e9
+        pass_ms = acc["scatter_ms"] / K / max(passes, 1.0)     # HIP events around each k_radix_scatter launch
+        achieved = SCATTER_BYTES_PER_SPLAT * n / (pass_ms * 1e-3) / 1e9
         keysort_ms = (acc["keygen_ms"] + acc["sort_ms"]) / K
+        sort_bytes = sort_bytes_per_splat(int(round(passes)))
         out = {
             "metric": "splats_sorted_per_s (whole 1080p frame: keys+sort+project+bin+raster)",
             "value": n * K * world / elapsed,
@@ -191,13 +195,16 @@ def main():
                        "sharding": "camera views over replicated splats" + ("" if a.no_gather or world == 1 else " + RCCL framebuffer gather to rank 0")},
             "fps_1080p": K * world / elapsed,
             "sort_only_splats_per_s": n / (keysort_ms * 1e-3),
-            "sort_only_hbm_frac": SORT_TOTAL_BYTES_PER_SPLAT * n / (keysort_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-            "stage_ms": {k: acc[k] / K for k in ("select_ms", "keygen_ms", "sort_ms", "project_ms", "bin_ms", "raster_ms", "total_ms")},
+            "sort_only_ms": keysort_ms,
+            "sort_only_bytes_per_splat": sort_bytes,
+            "sort_only_hbm_frac": sort_bytes * n / (keysort_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "sort_only_hbm_frac_at_92B": 92 * n / (keysort_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "stage_ms": {k: acc[k] / K for k in ("select_ms", "keygen_ms", "sort_ms", "scatter_ms", "project_ms", "bin_ms", "raster_ms", "total_ms")},
             "tile_pairs": int(acc["tile_pairs"] / K),
-            "roofline": {"kernel": "k_sort_pass (one 8-bit onesweep pass)", "bound": "hbm", "achieved": achieved,
+            "roofline": {"kernel": "k_radix_scatter<u32> (one stable radix scatter pass of the depth sort)", "bound": "hbm", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "avg_launch_ms": pass_ms, "launches_per_step": passes,
-                         "algorithmic_bytes_per_launch": SORT_PASS_BYTES_PER_SPLAT * n},
+                         "algorithmic_bytes_per_launch": SCATTER_BYTES_PER_SPLAT * n},
         }
         if a.cpu_frames > 0:
             v, secs = cpu_baseline(splats, views, a.cpu_frames)

@@ -25,6 +25,9 @@ ABI_SYMBOLS = [
     "gsx_set_lod_hc", "gsx_select_octree", "gsx_select_hc", "gsx_get_selection", "gsx_sort", "gsx_get_sorted_dev",
     "gsx_get_keys", "gsx_render", "gsx_get_framebuffer_dev",
     "gsx_host_convert_raw", "gsx_host_load_splat_file", "gsx_host_free", "gsx_host_camera", "gsx_host_orbit_pose",
+    "gsx_host_octree_build", "gsx_host_hc_build", "gsx_host_gridhc_build", "gsx_host_lod_free", "gsx_host_lod_size",
+    "gsx_host_lod_roots", "gsx_host_lod_cells", "gsx_host_lod_splats", "gsx_host_lod_flat_octree", "gsx_host_lod_flat_hc",
+    "gsx_host_lod_cut_depth", "gsx_host_lod_cut_camera",
 ]
 
 
@@ -46,7 +49,7 @@ class HcFlat(C.Structure):
 
 
 class Timings(C.Structure):
-    _fields_ = [("select_ms", C.c_float), ("keygen_ms", C.c_float), ("sort_ms", C.c_float), ("project_ms", C.c_float),
+    _fields_ = [("select_ms", C.c_float), ("keygen_ms", C.c_float), ("sort_ms", C.c_float), ("scatter_ms", C.c_float), ("project_ms", C.c_float),
                 ("bin_ms", C.c_float), ("raster_ms", C.c_float), ("total_ms", C.c_float), ("sort_passes", C.c_uint32),
                 ("sort_launches", C.c_uint32), ("tile_pairs", C.c_uint64)]
 

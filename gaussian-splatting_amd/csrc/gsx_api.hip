@@ -153,6 +153,8 @@ int gsx_get_timings(gsx_ctx* c, gsx_timings* out) {
         if (c->ev_recorded[EV_SORT1]) {
             t.keygen_ms = ev_ms(c, EV_KEY0, EV_KEY1);
             t.sort_ms = ev_ms(c, EV_KEY1, EV_SORT1);
+            t.scatter_ms = 0.0f;
+            for (uint32_t p = 0; p < c->sort_passes && p < 4; ++p) t.scatter_ms += ev_ms(c, EV_X0 + 2 * p, EV_X0 + 2 * p + 1);
         }
         if (c->ev_recorded[EV_RAST1]) {
             t.project_ms = ev_ms(c, EV_PROJ0, EV_PROJ1);

@@ -116,13 +116,14 @@ struct gsx_ctx {
     uint64_t pair_ws_words = 0;
 
     // timing
-    hipEvent_t ev[16] = {};
-    bool ev_recorded[16] = {};
+    hipEvent_t ev[24] = {};
+    bool ev_recorded[24] = {};
     gsx_timings tim = {};
 };
 
 enum GsxEvent {
-    EV_SEL0 = 0, EV_SEL1, EV_KEY0, EV_KEY1, EV_SORT1, EV_PROJ0, EV_PROJ1, EV_BIN1, EV_RAST1, EV_COUNT
+    EV_SEL0 = 0, EV_SEL1, EV_KEY0, EV_KEY1, EV_SORT1, EV_PROJ0, EV_PROJ1, EV_BIN1, EV_RAST1,
+    EV_X0, /* 4 passes x (start, stop) */ EV_X_END = EV_X0 + 8, EV_COUNT = EV_X_END
 };
 
 #define GSX_HIP(ctx, call)                                                        \

@@ -179,19 +179,21 @@ static void key_bounds(const gsx_ctx* c, uint32_t* key_lo, uint32_t* key_span) {
 
 template <typename KeyT, int NT, int IPT>
 static void launch_pass(gsx_ctx* c, hipStream_t st, uint32_t g, const KeyT* kin, const uint32_t* vin, KeyT* kout, uint32_t* vout,
-                        const uint32_t* count_ptr, uint32_t shift, uint32_t bits, uint32_t* ws, bool need_hist, bool iota) {
+                        const uint32_t* count_ptr, uint32_t shift, uint32_t bits, uint32_t* ws, bool need_hist, bool iota,
+                        int ev_pass /* -1 = no events */) {
     uint32_t* cnt = ws;
     uint32_t* totals = ws + static_cast<uint64_t>(GSX_RADIX_MAX_DIGITS) * g;
     if (need_hist)
         hipLaunchKernelGGL((k_radix_hist<KeyT, NT>), dim3(g), dim3(NT), 0, st, kin, count_ptr, shift, bits, cnt);
     hipLaunchKernelGGL((k_radix_scan<0>), dim3(1u << bits), dim3(256), 0, st, cnt, g, totals);
+    if (ev_pass >= 0) (void)hipEventRecord(c->ev[EV_X0 + 2 * ev_pass], st);
     if (iota)
         hipLaunchKernelGGL((k_radix_scatter<KeyT, NT, IPT, true>), dim3(g), dim3(NT), 0, st, kin, vin, kout, vout, count_ptr, shift,
                            bits, cnt, totals);
     else
         hipLaunchKernelGGL((k_radix_scatter<KeyT, NT, IPT, false>), dim3(g), dim3(NT), 0, st, kin, vin, kout, vout, count_ptr, shift,
                            bits, cnt, totals);
-    (void)c;
+    if (ev_pass >= 0) (void)hipEventRecord(c->ev[EV_X0 + 2 * ev_pass + 1], st);
 }
 
 int gsx_launch_sort(gsx_ctx* c) {
@@ -216,7 +218,7 @@ int gsx_launch_sort(gsx_ctx* c) {
         const bool first = p == 0;
         launch_pass<uint32_t, GSX_SORT_NT, GSX_SORT_IPT>(c, c->stream, g, c->keys[cur], first ? c->sel_idx : c->vals[cur], c->keys[cur ^ 1],
                                                           c->vals[cur ^ 1], c->m_dev, plan.shift[p], plan.bits[p], c->sort_ws,
-                                                          /*need_hist=*/!first, /*iota=*/first && c->sel_iota);
+                                                          /*need_hist=*/!first, /*iota=*/first && c->sel_iota, c->profiling ? p : -1);
         cur ^= 1;
     }
     if (c->profiling) GSX_HIP(c, hipEventRecord(c->ev[EV_SORT1], c->stream));

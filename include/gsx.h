@@ -78,7 +78,8 @@ typedef struct gsx_hc_flat {
 typedef struct gsx_timings {
     float select_ms;   /* LOD cut kernels */
     float keygen_ms;   /* depth keys + digit histograms */
-    float sort_ms;     /* radix passes only */
+    float sort_ms;     /* radix passes only (count + scan + scatter kernels and the gaps between them) */
+    float scatter_ms;  /* inside sort_ms: the k_radix_scatter launches alone (sort_passes launches) */
     float project_ms;
     float bin_ms;
     float raster_ms;
@@ -162,6 +163,33 @@ int gsx_host_camera(const float world16[16], float fov_deg, float aspect, float 
  * Node::rotate(axis_i, angle_i) calls on the orbit node (OrbitCamera.h:24-30,
  * Node.cpp:10-27, main.cpp:469-486). */
 int gsx_host_orbit_pose(float distance, const float* axes3, const float* angles, uint32_t n_rot, float world16[16]);
+
+/* ---- host-side LOD structures: Octree (Octree.cpp:33-187), HC (HC.cpp:4-98), GridHC
+ * (GridHC.cpp:10-74) built on the CPU exactly as the reference builds them at load time
+ * (SplatMeshOctree.hpp:57-79, SplatMeshHC.hpp:58-91, SplatMeshGridHC.cpp:26-52), then
+ * flattened for gsx_set_lod_octree / gsx_set_lod_hc. ---- */
+typedef struct gsx_lod gsx_lod;
+int gsx_host_octree_build(const void* raw32_host, uint64_t n, int center, gsx_lod** out);
+int gsx_host_hc_build(const void* aos80_host, uint64_t n, gsx_lod** out);
+int gsx_host_gridhc_build(const void* aos80_host, uint64_t n, uint32_t sx, uint32_t sy, uint32_t sz, gsx_lod** out);
+void gsx_host_lod_free(gsx_lod* lod);
+uint64_t gsx_host_lod_size(const gsx_lod* lod);    /* number of splats (= nodes) the structure generated */
+uint64_t gsx_host_lod_roots(const gsx_lod* lod);   /* HC / GridHC: roots left in HC::nodes */
+uint64_t gsx_host_lod_cells(const gsx_lod* lod);   /* GridHC: non-empty cells */
+int gsx_host_lod_splats(const gsx_lod* lod, void* aos80_out_host);   /* Octree::splats / HC::splats / GridHC::splats */
+/* Any output pointer may be NULL. */
+int gsx_host_lod_flat_octree(const gsx_lod* lod, float* center3, float* half3, uint32_t* parent, uint8_t* is_leaf,
+                             uint32_t* first_child, uint32_t* n_children);
+int gsx_host_lod_flat_hc(const gsx_lod* lod, uint32_t* parent, uint8_t* is_leaf, float* error, float* weight,
+                         uint32_t* child2, uint32_t* roots, uint32_t* cell_root_start);
+/* View-independent cuts, in the reference's output order: Octree::get_indices_depth
+ * (Octree.hpp:131-162), HC::get_indices_depth (HC.cpp:134-168), GridHC::get_indices_error
+ * (GridHC.cpp:76-92).  Feed the result to gsx_select_list. */
+int gsx_host_lod_cut_depth(gsx_lod* lod, uint32_t depth, uint32_t* idx_out_host, uint64_t capacity, uint64_t* m_out);
+/* CPU evaluation of the camera-dependent cuts (Octree::get_indices, HC/GridHC::get_indices), kept
+ * for hosts without a GPU context at hand; the per-frame path is gsx_select_octree / gsx_select_hc. */
+int gsx_host_lod_cut_camera(gsx_lod* lod, const float world16[16], float fov_deg, float aspect, float znear, float zfar,
+                            float threshold, uint32_t* idx_out_host, uint64_t capacity, uint64_t* m_out);
 
 #ifdef __cplusplus
 }
