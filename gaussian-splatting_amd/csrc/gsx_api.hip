@@ -381,7 +381,7 @@ int gsx_get_keys(gsx_ctx* c, const float cam_pos[3], float* dist_out_host, uint3
 int gsx_render(gsx_ctx* c, const gsx_uniforms* u, uint32_t width, uint32_t height, uint32_t y0, uint32_t y1,
                void* rgba8_out_host) {
     if (!c || !u || width == 0 || height == 0 || y0 >= y1 || y1 > height) return GSX_E_INVALID;
-    if (width > 16384 || height > 16384) return GSX_E_INVALID;
+    if (width > 4096 || height > 4096) { c->err = "frame larger than 4096 x 4096"; return GSX_E_UNSUPPORTED; }
     if (!c->sorted_valid) { c->err = "gsx_render before gsx_sort"; return GSX_E_STATE; }
     int rc = set_device(c);
     if (rc) return rc;
@@ -395,6 +395,14 @@ int gsx_render(gsx_ctx* c, const gsx_uniforms* u, uint32_t width, uint32_t heigh
     }
     return GSX_OK;
 }
+
+#ifdef GSX_DEBUG_COUNT
+int gsx_debug_flags(gsx_ctx* c, uint32_t out[8]) {
+    GSX_HIP(c, hipMemcpy(out, c->flags, 32, hipMemcpyDeviceToHost));
+    GSX_HIP(c, hipMemset(c->flags, 0, 32));
+    return GSX_OK;
+}
+#endif
 
 int gsx_get_framebuffer_dev(gsx_ctx* c, const void** rgba8_dev, uint32_t* width, uint32_t* height) {
     if (!c || !rgba8_dev) return GSX_E_INVALID;

@@ -170,18 +170,44 @@ __global__ __launch_bounds__(GSX_BIN_NT) void k_bin(const uint32_t* __restrict__
         if (threadIdx.x == 0) block_sums[blockIdx.x] = block_total;
         return;
     }
-    uint64_t pos = static_cast<uint64_t>(block_sums[blockIdx.x]) + excl;
+    // Emit cooperatively: the block's pairs occupy [block_base, block_base + block_total) in rank
+    // order; every thread fills slots tid, tid + NT, ... (coalesced stores) and finds the owning
+    // rank by binary search in the per-rank offsets held in LDS.
+    __shared__ uint32_t s_off[GSX_BIN_TILE + 1];     // exclusive offsets per rank of this block
+    __shared__ uint32_t s_box[GSX_BIN_TILE];         // tx0 | ty0 << 8 | width << 16
+    __shared__ uint32_t s_pay[GSX_BIN_TILE];
+    {
+        uint32_t run = excl;
 #pragma unroll
-    for (int j = 0; j < GSX_BIN_IPT; ++j) {
-        if (cnt[j] == 0) continue;
-        if (pos + cnt[j] > pair_cap) { atomicOr(&flags->pair_overflow, 1u); return; }
-        const uint32_t payload = RANK_PAYLOAD ? (base + j) : idx[j];
-        for (uint32_t ty = by0[j]; ty <= by1[j]; ++ty)
-            for (uint32_t tx = bx0[j]; tx <= bx1[j]; ++tx) {
-                pair_key[pos] = static_cast<uint16_t>(ty * vp.tiles_x + tx);
-                pair_val[pos] = payload;
-                ++pos;
+        for (int j = 0; j < GSX_BIN_IPT; ++j) {
+            const uint32_t r = threadIdx.x * GSX_BIN_IPT + j;
+            s_off[r] = run;
+            run += cnt[j];
+            if (cnt[j]) {
+                s_box[r] = bx0[j] | (by0[j] << 8) | ((bx1[j] - bx0[j] + 1) << 16);
+                s_pay[r] = RANK_PAYLOAD ? (base + j) : idx[j];
             }
+        }
+        if (threadIdx.x == GSX_BIN_NT - 1) s_off[GSX_BIN_TILE] = run;
+    }
+    __syncthreads();
+    const uint64_t block_base = block_sums[blockIdx.x];
+    if (block_base + block_total > pair_cap) {
+        if (threadIdx.x == 0) atomicOr(&flags->pair_overflow, 1u);
+        return;
+    }
+    for (uint32_t slot = threadIdx.x; slot < block_total; slot += GSX_BIN_NT) {
+        uint32_t lo = 0, hi = GSX_BIN_TILE;          // last r with s_off[r] <= slot (skips empty ranks)
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (s_off[mid] <= slot) lo = mid; else hi = mid;
+        }
+        const uint32_t local = slot - s_off[lo], box = s_box[lo];
+        const uint32_t wx = box >> 16;
+        const uint32_t dy = local / wx, dx = local - dy * wx;
+        const uint32_t tx = (box & 0xFFu) + dx, ty = ((box >> 8) & 0xFFu) + dy;
+        pair_key[block_base + slot] = static_cast<uint16_t>(ty * vp.tiles_x + tx);
+        pair_val[block_base + slot] = s_pay[lo];
     }
 }
 
@@ -258,7 +284,7 @@ __device__ __forceinline__ uint32_t gsx_bayer(uint32_t x, uint32_t y, uint32_t b
 template <int MODE /*0 blend, 1 threshold (bayerSize 10), 2 bayer dither*/>
 __global__ __launch_bounds__(256) void k_raster(const uint32_t* __restrict__ tile_start, const uint32_t* __restrict__ pair_val,
                                                 const GsxProj* __restrict__ proj, const uint32_t* __restrict__ sorted_all,
-                                                GsxViewParams vp, uint8_t* __restrict__ fb) {
+                                                GsxViewParams vp, uint8_t* __restrict__ fb, GsxDevFlags* __restrict__ dbg) {
     __shared__ float4 s_a[GSX_RASTER_BATCH];  // cx cy ex ey
     __shared__ float4 s_m[GSX_RASTER_BATCH];  // m00 m01 m10 m11
     __shared__ float4 s_c[GSX_RASTER_BATCH];  // r g b a
@@ -316,6 +342,9 @@ __global__ __launch_bounds__(256) void k_raster(const uint32_t* __restrict__ til
             if (lane == 0 && wave_live) s_live = 1;
         }
         hi -= nb;
+#ifdef GSX_DEBUG_COUNT
+        if (tid == 0) atomicAdd(&dbg->pad[0], nb);
+#endif
         __syncthreads();
         if (!s_live) break;  // every pixel of the tile is saturated
     }
@@ -377,7 +406,10 @@ int gsx_launch_render(gsx_ctx* c, const gsx_uniforms* u, uint32_t w, uint32_t h,
     vp.bayer_size = u->bayerSize;
     vp.bayer_scale = u->bayerScale;
     const uint32_t n_tiles = vp.tiles_x * vp.tiles_y;
-    if (n_tiles > 65535u) { c->err = "more than 65535 tiles in one band"; return GSX_E_UNSUPPORTED; }
+    if (n_tiles > 65535u || vp.tiles_x > 256u || vp.tiles_y > 256u) {
+        c->err = "frame band larger than 4096 x 4096 pixels / 65535 tiles";
+        return GSX_E_UNSUPPORTED;
+    }
     const int mode = (u->bayerSize == 1u) ? 0 : (u->bayerSize == 10u ? 1 : 2);
     if (mode == 2 && !(u->bayerSize == 2u || u->bayerSize == 4u || u->bayerSize == 8u || u->bayerSize == 16u)) {
         c->err = "bayerSize must be 1, 10 or a power of two (the shader divides by zero otherwise)";
@@ -466,13 +498,13 @@ int gsx_launch_render(gsx_ctx* c, const gsx_uniforms* u, uint32_t w, uint32_t h,
     if (n_tiles > 0) {
         if (mode == 0)
             hipLaunchKernelGGL(k_raster<0>, dim3(n_tiles), dim3(256), 0, c->stream, c->tile_start, sorted_vals, c->proj, sorted,
-                               vp, c->fb);
+                               vp, c->fb, c->flags);
         else if (mode == 1)
             hipLaunchKernelGGL(k_raster<1>, dim3(n_tiles), dim3(256), 0, c->stream, c->tile_start, sorted_vals, c->proj, sorted,
-                               vp, c->fb);
+                               vp, c->fb, c->flags);
         else
             hipLaunchKernelGGL(k_raster<2>, dim3(n_tiles), dim3(256), 0, c->stream, c->tile_start, sorted_vals, c->proj, sorted,
-                               vp, c->fb);
+                               vp, c->fb, c->flags);
     }
     if (c->profiling) GSX_HIP(c, hipEventRecord(c->ev[EV_RAST1], c->stream));
     GSX_HIP(c, hipGetLastError());
