@@ -20,7 +20,7 @@ GSX_OK, GSX_E_INVALID, GSX_E_HIP, GSX_E_NOMEM, GSX_E_STATE, GSX_E_UNSUPPORTED, G
 
 # every symbol include/gsx.h declares
 ABI_SYMBOLS = [
-    "gsx_create", "gsx_destroy", "gsx_last_error", "gsx_sync", "gsx_set_profiling", "gsx_get_timings",
+    "gsx_create", "gsx_destroy", "gsx_last_error", "gsx_sync", "gsx_set_profiling", "gsx_get_timings", "gsx_set_option",
     "gsx_upload_splats", "gsx_upload_splats_dev", "gsx_select_all", "gsx_select_list", "gsx_set_lod_octree",
     "gsx_set_lod_hc", "gsx_select_octree", "gsx_select_hc", "gsx_get_selection", "gsx_sort", "gsx_get_sorted_dev",
     "gsx_get_keys", "gsx_render", "gsx_get_framebuffer_dev",
@@ -51,7 +51,7 @@ class HcFlat(C.Structure):
 class Timings(C.Structure):
     _fields_ = [("select_ms", C.c_float), ("keygen_ms", C.c_float), ("sort_ms", C.c_float), ("scatter_ms", C.c_float), ("project_ms", C.c_float),
                 ("bin_ms", C.c_float), ("raster_ms", C.c_float), ("total_ms", C.c_float), ("sort_passes", C.c_uint32),
-                ("sort_launches", C.c_uint32), ("tile_pairs", C.c_uint64)]
+                ("sort_launches", C.c_uint32), ("tile_pairs", C.c_uint64), ("render_iters", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 assert C.sizeof(Uniforms) == 224
@@ -213,6 +213,10 @@ class Gsx:
 
     def set_profiling(self, on=True):
         self._chk(self.lib.gsx_set_profiling(self.ctx, C.c_int(1 if on else 0)))
+
+    def set_option(self, name, value):
+        """Tuning knob of the frame loop (include/gsx.h gsx_set_option): pair_budget, chunk_first, chunk_growth."""
+        self._chk(self.lib.gsx_set_option(self.ctx, name.encode(), C.c_uint64(int(value))))
 
     def timings(self):
         t = Timings()

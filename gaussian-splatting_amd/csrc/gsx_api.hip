@@ -32,6 +32,8 @@ int set_device(gsx_ctx* c) {
 
 // Reads the device flag block (synchronises the stream).
 int check_flags(gsx_ctx* c) {
+    int frc = gsx_frame_finish(c);
+    if (frc) return frc;
     GSX_HIP(c, hipMemcpyAsync(c->flags_host, c->flags, sizeof(GsxDevFlags), hipMemcpyDeviceToHost, c->stream));
     GSX_HIP(c, hipStreamSynchronize(c->stream));
     if (c->flags_host->spin_expired) { c->err = "device: bounded look-back spin expired (results invalid)"; return GSX_E_INTERNAL; }
@@ -53,7 +55,7 @@ int alloc_scene(gsx_ctx* c, uint64_t n) {
     c->sort_cap = n;
     c->sort_ws_words = gsx_sort_workspace_words(n);
     if ((rc = dev_alloc(c, &c->sort_ws, c->sort_ws_words))) return rc;
-    if ((rc = dev_alloc(c, &c->proj, n))) return rc;
+    if ((rc = dev_alloc(c, &c->proj, n)) || (rc = dev_alloc(c, &c->tbox, n))) return rc;
     c->proj_cap = n;
     // LOD / list-selection scratch (flags padded for 16-byte vector loads)
     const uint64_t fl = (n + 15) / 16 * 16 + 16;
@@ -92,6 +94,11 @@ int gsx_create(int device, gsx_ctx** out) {
     }
     for (int i = 0; i < EV_COUNT; ++i)
         if (hipEventCreate(&c->ev[i]) != hipSuccess) return fail(GSX_E_HIP);
+    if (hipEventCreateWithFlags(&c->frame_ev, hipEventDisableTiming) != hipSuccess) return fail(GSX_E_HIP);
+    if (hipMalloc(reinterpret_cast<void**>(&c->ctl), sizeof(GsxFrameCtl)) != hipSuccess) return fail(GSX_E_NOMEM);
+    if (hipMalloc(reinterpret_cast<void**>(&c->live_bits), GSX_MAX_TILES_Y * GSX_LIVE_ROW_WORDS * 4) != hipSuccess) return fail(GSX_E_NOMEM);
+    if (hipHostMalloc(reinterpret_cast<void**>(&c->ctl_host), sizeof(GsxFrameCtl), hipHostMallocDefault) != hipSuccess)
+        return fail(GSX_E_NOMEM);
     if (hipMalloc(reinterpret_cast<void**>(&c->m_dev), 16) != hipSuccess) return fail(GSX_E_NOMEM);
     if (hipMalloc(reinterpret_cast<void**>(&c->pair_total_dev), 16) != hipSuccess) return fail(GSX_E_NOMEM);
     if (hipMalloc(reinterpret_cast<void**>(&c->aabb_dev), 32) != hipSuccess) return fail(GSX_E_NOMEM);
@@ -109,6 +116,7 @@ int gsx_create(int device, gsx_ctx** out) {
 int gsx_destroy(gsx_ctx* c) {
     if (!c) return GSX_E_INVALID;
     (void)hipSetDevice(c->device);
+    c->frame_pending = false;
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     dev_free(&c->pos4); dev_free(&c->covA); dev_free(&c->covB); dev_free(&c->color4);
     dev_free(&c->sel_idx); dev_free(&c->m_dev);
@@ -118,6 +126,9 @@ int gsx_destroy(gsx_ctx* c) {
     dev_free(&c->sort_ws); dev_free(&c->aabb_dev); dev_free(&c->flags); dev_free(&c->pair_ws);
     dev_free(&c->proj); dev_free(&c->splat_ntiles); dev_free(&c->scan_block_sums);
     dev_free(&c->tile_start); dev_free(&c->pair_total_dev); dev_free(&c->fb);
+    dev_free(&c->tbox); dev_free(&c->sub_off); dev_free(&c->ctl); dev_free(&c->live_bits); dev_free(&c->tile_state); dev_free(&c->accum);
+    if (c->ctl_host) (void)hipHostFree(c->ctl_host);
+    if (c->frame_ev) (void)hipEventDestroy(c->frame_ev);
     if (c->host_word) (void)hipHostFree(c->host_word);
     if (c->flags_host) (void)hipHostFree(c->flags_host);
     for (int i = 0; i < EV_COUNT; ++i)
@@ -136,6 +147,23 @@ int gsx_sync(gsx_ctx* c) {
     return check_flags(c);
 }
 
+int gsx_set_option(gsx_ctx* c, const char* name, uint64_t value) {
+    if (!c || !name) return GSX_E_INVALID;
+    if (!std::strcmp(name, "pair_budget")) {
+        if (value > 0x7FFFFFFFull) { c->err = "pair_budget above 2^31-1"; return GSX_E_INVALID; }
+        c->opt_pair_budget = value;
+    } else if (!std::strcmp(name, "chunk_first")) {
+        c->opt_chunk_first = value > 0x7FFFFFFFull ? 0x7FFFFFFFull : value;
+    } else if (!std::strcmp(name, "chunk_growth")) {
+        if (value == 1 || value > 1024) { c->err = "chunk_growth must be 0 or 2..1024"; return GSX_E_INVALID; }
+        c->opt_chunk_growth = value;
+    } else {
+        c->err = std::string("unknown option: ") + name;
+        return GSX_E_INVALID;
+    }
+    return GSX_OK;
+}
+
 int gsx_set_profiling(gsx_ctx* c, int enabled) {
     if (!c) return GSX_E_INVALID;
     c->profiling = enabled != 0;
@@ -146,6 +174,7 @@ int gsx_get_timings(gsx_ctx* c, gsx_timings* out) {
     if (!c || !out) return GSX_E_INVALID;
     int rc = set_device(c);
     if (rc) return rc;
+    if ((rc = gsx_frame_finish(c))) return rc;
     GSX_HIP(c, hipStreamSynchronize(c->stream));
     gsx_timings t = c->tim;
     if (c->profiling) {
@@ -158,8 +187,14 @@ int gsx_get_timings(gsx_ctx* c, gsx_timings* out) {
         }
         if (c->ev_recorded[EV_RAST1]) {
             t.project_ms = ev_ms(c, EV_PROJ0, EV_PROJ1);
-            t.bin_ms = ev_ms(c, EV_PROJ1, EV_BIN1);
-            t.raster_ms = ev_ms(c, EV_BIN1, EV_RAST1);
+            // the frame loop interleaves binning and rasterizing: sum the two halves of every iteration
+            t.bin_ms = 0.0f; t.raster_ms = 0.0f;
+            int prev = EV_PROJ1;
+            for (uint32_t k = 0; k < c->frame.n_iters && k < GSX_MAX_SCHED; ++k) {
+                t.bin_ms += ev_ms(c, prev, EV_IT0 + 2 * k);
+                t.raster_ms += ev_ms(c, EV_IT0 + 2 * k, EV_IT0 + 2 * k + 1);
+                prev = EV_IT0 + 2 * k + 1;
+            }
         }
         t.total_ms = t.select_ms + t.keygen_ms + t.sort_ms + t.project_ms + t.bin_ms + t.raster_ms;
     }
@@ -173,6 +208,7 @@ int gsx_get_timings(gsx_ctx* c, gsx_timings* out) {
 
 static int upload_common(gsx_ctx* c, const void* aos_dev, uint64_t n) {
     int rc;
+    if ((rc = gsx_frame_finish(c))) return rc;
     if ((rc = alloc_scene(c, n))) return rc;
     c->n = n;
     GSX_HIP(c, hipMemsetAsync(c->flags, 0, sizeof(GsxDevFlags), c->stream));
@@ -218,6 +254,7 @@ int gsx_select_all(gsx_ctx* c) {
     if (!c) return GSX_E_INVALID;
     int rc = set_device(c);
     if (rc) return rc;
+    if ((rc = gsx_frame_finish(c))) return rc;
     c->sel_iota = true;
     c->m_cap = static_cast<uint32_t>(c->n);
     c->sorted_valid = false;
@@ -232,6 +269,7 @@ int gsx_select_list(gsx_ctx* c, const uint32_t* idx_host, uint32_t m) {
     if (m > c->n) { c->err = "selection longer than the scene"; return GSX_E_INVALID; }
     int rc = set_device(c);
     if (rc) return rc;
+    if ((rc = gsx_frame_finish(c))) return rc;
     if (m) GSX_HIP(c, hipMemcpyAsync(c->vals[0], idx_host, static_cast<uint64_t>(m) * 4, hipMemcpyHostToDevice, c->stream));
     if ((rc = gsx_launch_sort_list(c, m))) return rc;
     c->sel_iota = false;
@@ -303,6 +341,7 @@ int gsx_select_octree(gsx_ctx* c, const float viewproj[16], float min_screen_are
     if (c->lod_kind != 1) { c->err = "gsx_select_octree without gsx_set_lod_octree"; return GSX_E_STATE; }
     int rc = set_device(c);
     if (rc) return rc;
+    if ((rc = gsx_frame_finish(c))) return rc;
     if ((rc = gsx_launch_select_octree(c, viewproj, min_screen_area))) return rc;
     return finish_select(c, m_out);
 }
@@ -312,6 +351,7 @@ int gsx_select_hc(gsx_ctx* c, const float cam_pos[3], float threshold, uint32_t*
     if (c->lod_kind != 2) { c->err = "gsx_select_hc without gsx_set_lod_hc"; return GSX_E_STATE; }
     int rc = set_device(c);
     if (rc) return rc;
+    if ((rc = gsx_frame_finish(c))) return rc;
     if ((rc = gsx_launch_select_hc(c, cam_pos, threshold))) return rc;
     return finish_select(c, m_out);
 }
@@ -338,6 +378,7 @@ int gsx_sort(gsx_ctx* c, const float cam_pos[3], uint32_t* idx_out_host) {
     if (!c || !cam_pos) return GSX_E_INVALID;
     int rc = set_device(c);
     if (rc) return rc;
+    if ((rc = gsx_frame_finish(c))) return rc;   // the frame in flight still reads the last permutation
     c->cam[0] = cam_pos[0]; c->cam[1] = cam_pos[1]; c->cam[2] = cam_pos[2];
     if ((rc = gsx_launch_sort(c))) return rc;
     c->ev_recorded[EV_SORT1] = c->profiling;
@@ -367,6 +408,7 @@ int gsx_get_keys(gsx_ctx* c, const float cam_pos[3], float* dist_out_host, uint3
     int rc = set_device(c);
     if (rc) return rc;
     if (capacity < c->m_cap) { c->err = "key buffer too small"; return GSX_E_INVALID; }
+    if ((rc = gsx_frame_finish(c))) return rc;
     c->cam[0] = cam_pos[0]; c->cam[1] = cam_pos[1]; c->cam[2] = cam_pos[2];
     c->sorted_valid = false;  // keys[0] doubles as scratch here
     float* dev = reinterpret_cast<float*>(c->keys[0]);
@@ -385,6 +427,7 @@ int gsx_render(gsx_ctx* c, const gsx_uniforms* u, uint32_t width, uint32_t heigh
     if (!c->sorted_valid) { c->err = "gsx_render before gsx_sort"; return GSX_E_STATE; }
     int rc = set_device(c);
     if (rc) return rc;
+    if ((rc = gsx_frame_finish(c))) return rc;
     if ((rc = gsx_launch_render(c, u, width, height, y0, y1))) return rc;
     c->ev_recorded[EV_RAST1] = c->profiling;
     if (rgba8_out_host) {
@@ -397,6 +440,28 @@ int gsx_render(gsx_ctx* c, const gsx_uniforms* u, uint32_t width, uint32_t heigh
 }
 
 #ifdef GSX_DEBUG_COUNT
+int gsx_debug_read(gsx_ctx* c, int what, void* out, uint64_t bytes) {
+    const void* src = nullptr;
+    switch (what) {
+        case 1: src = c->tile_start; break;
+        case 2: src = c->pair_val[0]; break;
+        case 3: src = c->pair_key[0]; break;
+        case 4: src = c->pair_val[1]; break;
+        case 5: src = c->pair_key[1]; break;
+        case 6: src = c->sub_off; break;
+        case 7: src = c->scan_block_sums; break;
+        case 8: src = c->ctl; break;
+        case 9: src = c->tbox; break;
+        case 10: src = c->tile_state; break;
+        case 11: src = c->live_bits; break;
+        case 12: src = c->proj; break;
+        case 13: src = c->accum; break;
+        default: return GSX_E_INVALID;
+    }
+    GSX_HIP(c, hipStreamSynchronize(c->stream));
+    GSX_HIP(c, hipMemcpy(out, src, bytes, hipMemcpyDeviceToHost));
+    return GSX_OK;
+}
 int gsx_debug_flags(gsx_ctx* c, uint32_t out[8]) {
     GSX_HIP(c, hipMemcpy(out, c->flags, 32, hipMemcpyDeviceToHost));
     GSX_HIP(c, hipMemset(c->flags, 0, 32));

@@ -26,6 +26,34 @@
 #define GSX_TILE_W 16
 #define GSX_TILE_H 16
 
+#define GSX_MAX_TILES_Y 256          // frame bands up to 4096 rows
+#define GSX_LIVE_ROW_WORDS 8         // 256 tiles per row as bits
+#define GSX_TBOX_NONE 0x000000FFu    // packed tile box with tx0 > tx1: splat culled
+#define GSX_MAX_SCHED 8              // scheduled near -> far iterations per frame
+#define GSX_CTL_CURSORS (GSX_MAX_SCHED + 1)
+
+// Device-resident control block of the frame loop (gsx_raster.hip).
+struct GsxFrameCtl {
+    uint32_t cursor[GSX_CTL_CURSORS];  // ranks consumed from the near end before iteration k
+    uint32_t n_blocks;     // 1024-rank blocks of the current iteration that fit the pair budget
+    uint32_t pairs;        // pairs of the current iteration
+    uint32_t live_tiles;   // tiles not yet saturated
+    uint32_t m;            // selection size of the frame
+    uint32_t total_pairs;  // over all iterations (saturating)
+    uint32_t max_pairs;    // largest iteration
+    uint32_t iters_used;   // iterations that emitted pairs
+    uint32_t stall;        // an iteration whose nearest block alone exceeds the budget
+};
+
+// Host-side description of the frame in flight (for gsx_frame_finish).
+struct GsxFrameState {
+    alignas(16) unsigned char vp_blob[192];
+    int mode = 0;
+    uint32_t n_tiles = 0;
+    uint32_t n_iters = 0;
+    bool continuing = false;
+};
+
 // Error/diagnostic words written by kernels (never zeroed implicitly).
 struct GsxDevFlags {
     uint32_t spin_expired;   // a bounded look-back spin ran out
@@ -114,16 +142,34 @@ struct gsx_ctx {
     uint32_t fb_w = 0, fb_h = 0;
     uint32_t* pair_ws = nullptr;       // radix workspace of the pair sort
     uint64_t pair_ws_words = 0;
+    uint64_t pair_alloc = 0;           // allocated pairs per buffer (pair_cap = budget in use <= pair_alloc)
+    uint64_t pair_grown = 0;           // budget a frame had to grow to (kept for later frames)
+    uint32_t* sub_off = nullptr;       // per count block: 17 in-block pair offsets (64-rank boundaries)
+    uint64_t sub_off_cap = 0;
+    uint32_t* tbox = nullptr;          // per splat: packed tile box (capacity proj_cap)
+    GsxFrameCtl* ctl = nullptr;
+    GsxFrameCtl* ctl_host = nullptr;   // pinned copy read after the frame
+    uint32_t* live_bits = nullptr;     // GSX_MAX_TILES_Y x GSX_LIVE_ROW_WORDS: tiles still unsaturated
+    uint32_t* tile_state = nullptr;    // per tile: 0 untouched, 1 accumulators valid, 2 retired
+    uint64_t tile_state_cap = 0;
+    float4* accum = nullptr;           // per tile x 256 pixels: (r, g, b, transmittance)
+    uint64_t accum_cap = 0;
+    GsxFrameState frame;
+    hipEvent_t frame_ev = nullptr;
+    bool frame_pending = false;
+    // tuning (gsx_set_option); 0 = automatic
+    uint64_t opt_pair_budget = 0, opt_chunk_first = 0, opt_chunk_growth = 0;
 
     // timing
-    hipEvent_t ev[24] = {};
-    bool ev_recorded[24] = {};
+    hipEvent_t ev[40] = {};
+    bool ev_recorded[40] = {};
     gsx_timings tim = {};
 };
 
 enum GsxEvent {
     EV_SEL0 = 0, EV_SEL1, EV_KEY0, EV_KEY1, EV_SORT1, EV_PROJ0, EV_PROJ1, EV_BIN1, EV_RAST1,
-    EV_X0, /* 4 passes x (start, stop) */ EV_X_END = EV_X0 + 8, EV_COUNT = EV_X_END
+    EV_X0, /* 4 passes x (start, stop) */ EV_X_END = EV_X0 + 8,
+    EV_IT0 = EV_X_END, /* per scheduled iteration: (binned, rastered) */ EV_IT_END = EV_IT0 + 2 * GSX_MAX_SCHED, EV_COUNT = EV_IT_END
 };
 
 #define GSX_HIP(ctx, call)                                                        \
@@ -169,3 +215,4 @@ int gsx_launch_select_octree(gsx_ctx* c, const float vp[16], float thr);
 int gsx_launch_select_hc(gsx_ctx* c, const float cam[3], float thr);
 int gsx_launch_sort_list(gsx_ctx* c, uint32_t m); // ascending re-order of an explicit index list
 int gsx_launch_render(gsx_ctx* c, const gsx_uniforms* u, uint32_t w, uint32_t h, uint32_t y0, uint32_t y1);
+int gsx_frame_finish(gsx_ctx* c);                // waits for the queued frame; runs extra iterations if ranks are left

@@ -86,7 +86,9 @@ typedef struct gsx_timings {
     float total_ms;    /* first to last recorded event of the frame */
     uint32_t sort_passes;   /* radix passes actually executed (constant-digit passes are skipped) */
     uint32_t sort_launches; /* kernel launches inside sort_ms */
-    uint64_t tile_pairs;    /* (tile, splat) pairs produced by the binner */
+    uint64_t tile_pairs;    /* (tile, splat) pairs the binner emitted (after occlusion culling) */
+    uint32_t render_iters;  /* near -> far iterations of the frame that emitted pairs */
+    uint32_t reserved;
 } gsx_timings;
 
 /* ---- lifecycle (replaces Renderer::init device bring-up, renderer.cpp:3-100) ---- */
@@ -97,6 +99,13 @@ int gsx_sync(gsx_ctx* ctx);
 /* 1 = record HIP events around every stage (gsx_get_timings). Default 0. */
 int gsx_set_profiling(gsx_ctx* ctx, int enabled);
 int gsx_get_timings(gsx_ctx* ctx, gsx_timings* out);
+/* Tuning knobs of the frame loop (no counterpart in the reference; 0 restores the default):
+ *   "pair_budget"   (tile, splat) pairs one near -> far iteration may emit (sizes the pair buffers,
+ *                   12 bytes per pair); the device cuts iterations to fit and a frame that needs
+ *                   more simply runs more iterations
+ *   "chunk_first"   ranks of the first (nearest) iteration;  "chunk_growth"  window growth factor
+ * Unknown name -> GSX_E_INVALID. */
+int gsx_set_option(gsx_ctx* ctx, const char* name, uint64_t value);
 
 /* ---- scene upload: SplatMesh::initializeSplatBuffer (SplatMesh.h:139-147).
  * aos80 = n reference `Splat` records (Splat.h:19-29: mat4 transform, vec4
