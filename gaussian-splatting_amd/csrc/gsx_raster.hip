@@ -22,6 +22,8 @@
 // tile stop as soon as every pixel's transmittance is below 2^-11 (bounded
 // error < 0.13/255).
 #include <cstddef>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "gsx_internal.h"
@@ -209,7 +211,11 @@ __device__ __forceinline__ uint32_t gsx_rank_pairs(uint32_t local, uint32_t win,
     const uint32_t idx = sorted[r];
     const uint32_t tb = tbox[idx];
     const uint32_t tx0 = tb & 0xFFu, ty0 = (tb >> 8) & 0xFFu, tx1 = (tb >> 16) & 0xFFu, ty1 = tb >> 24;
+#ifdef GSX_DBG_NOCULL
+    if (tx0 > tx1) return 0u;
+#else
     if (tx0 > tx1 || !gsx_box_live(s_live, lw, tx0, tx1, ty0, ty1)) return 0u;
+#endif
     box = tx0 | (ty0 << 8) | ((tx1 - tx0 + 1u) << 16);
     pay = RANK_PAYLOAD ? r : idx;
     return (tx1 - tx0 + 1u) * (ty1 - ty0 + 1u);
@@ -407,7 +413,9 @@ __global__ __launch_bounds__(256) void k_tile_ranges(const uint16_t* __restrict_
 // ---------------------------------------------------------------------------
 #define GSX_RASTER_BATCH 256
 #define GSX_RASTER_CHECK 8           // a wave re-checks "all my pixels saturated" every this many shaded splats
+#ifndef GSX_T_EPS
 #define GSX_T_EPS (1.0f / 2048.0f)
+#endif
 
 // wgsl:75-117
 __device__ __forceinline__ uint32_t gsx_bayer(uint32_t x, uint32_t y, uint32_t bsize, uint32_t state) {
@@ -548,7 +556,8 @@ __global__ __launch_bounds__(256) void k_raster(const uint32_t* __restrict__ til
     __syncthreads();
     if (tid == 0) s_live[1] = 0;
     __syncthreads();
-    if (lane == 0 && __builtin_amdgcn_ballot_w64(T >= GSX_T_EPS) != 0) s_live[1] = 1;
+    const bool any_live = __builtin_amdgcn_ballot_w64(T >= GSX_T_EPS) != 0;   // every lane votes: keep it outside the lane-0 branch
+    if (lane == 0 && any_live) s_live[1] = 1;
     __syncthreads();
     if (s_live[1]) {
         *acc = make_float4(cr, cg, cb, T);
@@ -558,6 +567,9 @@ __global__ __launch_bounds__(256) void k_raster(const uint32_t* __restrict__ til
         atomicAnd(&live_bits[tty * ((vp.tiles_x + 31u) / 32u) + (ttx >> 5)], ~(1u << (ttx & 31u)));
         atomicSub(&ctl->live_tiles, 1u);
     }
+#ifdef GSX_DEBUG_COUNT
+    if (!s_live[1]) *acc = make_float4(cr, cg, cb, T);
+#endif
     // the framebuffer always holds the composite of everything drawn so far over the clear colour
     if (inside) {
         cr += T * 0.05f; cg += T * 0.05f; cb += T * 0.05f;
@@ -775,9 +787,15 @@ int gsx_frame_finish(gsx_ctx* c) {
     GSX_HIP(c, hipEventSynchronize(c->frame_ev));
     GsxFrameState& f = c->frame;
     uint32_t last = f.n_iters;
+    static const bool trace = std::getenv("GSX_TRACE") != nullptr;
     for (int guard = 0; ; ++guard) {
         const GsxFrameCtl& h = *c->ctl_host;
         const uint32_t cur = h.cursor[last];
+        if (trace)
+            std::fprintf(stderr, "[gsx] frame: iters=%u last=%u cursor=%u m=%u live=%u pairs=%u total=%u max=%u used=%u stall=%u budget=%llu opt=%llu grown=%llu alloc=%llu ctx=%p\n",
+                         f.n_iters, last, cur, h.m, h.live_tiles, h.pairs, h.total_pairs, h.max_pairs, h.iters_used, h.stall,
+                         static_cast<unsigned long long>(c->pair_cap), static_cast<unsigned long long>(c->opt_pair_budget),
+                         static_cast<unsigned long long>(c->pair_grown), static_cast<unsigned long long>(c->pair_alloc), static_cast<void*>(c));
         if (cur >= h.m || h.live_tiles == 0u) break;
         if (guard > 100000) { c->err = "frame did not complete"; c->frame_pending = false; return GSX_E_INTERNAL; }
         f.continuing = true;

@@ -66,5 +66,13 @@ def gsx(pkg):
     g.close()
 
 
+@pytest.fixture
+def gsx_fresh(pkg):
+    """A context of its own (for tests that change gsx_set_option knobs)."""
+    g = pkg.Gsx(0)
+    yield g
+    g.close()
+
+
 def bits(a):
     return np.ascontiguousarray(a, np.float32).view(np.uint32)

@@ -131,3 +131,87 @@ def test_render_rejects_bad_arguments(gsx, pkg, oracle, synth):
     with pytest.raises(pkg.GsxError) as e:
         gsx.render(pkg.make_uniforms(proj, view, bayerSize=3), 64, 64)
     assert e.value.code == pkg.GSX_E_UNSUPPORTED
+
+
+def test_render_repeated_frames_on_one_context(gsx, pkg, oracle, synth):
+    # a viewer renders frame after frame on one context: nothing (tile state, accumulators, LDS leftovers)
+    # may leak from one frame into the next
+    w, h = 256, 192
+    splats = scene(oracle, synth, 3000, seed=11)
+    gsx.upload(splats)
+    first = {}
+    for rnd in range(3):
+        for steps in (0, 4):
+            view, proj, cam = camera(oracle, w, h, steps)
+            perm = gsx.sort(cam)
+            img = gsx.render(pkg.make_uniforms(proj, view), w, h)
+            if steps not in first:
+                check_image(img, oracle.render(splats, perm, orc.make_uniforms(proj, view), w, h))
+                first[steps] = img.copy()
+            assert np.array_equal(img, first[steps]), f"frame changed on round {rnd}"
+
+
+def dense_scene(oracle, synth, n, seed):
+    # large opaque-ish splats: every tile saturates after a few dozen splats, so tiles retire and the
+    # binner's occlusion culling is what the frame depends on
+    return oracle.raw_to_splat(synth.clustered_cloud(n, seed=seed, n_clusters=6, sigma=0.5, frac=0.8, centre_extent=1.0, scale_mul=5.0))
+
+
+@pytest.mark.parametrize("opts", [
+    {},                                                            # default schedule (one iteration at this size)
+    {"chunk_first": 256, "chunk_growth": 2},                       # 8 scheduled iterations
+    {"chunk_first": 512, "chunk_growth": 2, "pair_budget": 20000},  # budget-cut iterations + continuation on the host
+    {"chunk_first": 1024, "pair_budget": 64},                      # nearest block alone exceeds the budget: buffers grow
+])
+def test_render_iterations_and_pair_budget(gsx_fresh, pkg, oracle, synth, opts):
+    gsx = gsx_fresh
+    w, h = 240, 176
+    splats = dense_scene(oracle, synth, 20000, seed=5)
+    view, proj, cam = camera(oracle, w, h, steps=2)
+    for k, v in opts.items():
+        gsx.set_option(k, v)
+    gsx.upload(splats)
+    perm = gsx.sort(cam)
+    img = gsx.render(pkg.make_uniforms(proj, view), w, h)
+    t = gsx.timings()
+    ref = oracle.render(splats, perm, orc.make_uniforms(proj, view), w, h)
+    check_image(img, ref)
+    assert ref[..., :3].std() > 5
+    if "chunk_first" in opts and "pair_budget" not in opts:
+        assert t["render_iters"] >= 2                              # later iterations skip what is hidden
+    # same frame again, and a tile band of it, on the same context
+    assert np.array_equal(gsx.render(pkg.make_uniforms(proj, view), w, h), img)
+    band = np.zeros_like(img)
+    gsx.render(pkg.make_uniforms(proj, view), w, h, 32, 112, out=band)
+    if "pair_budget" in opts:
+        # iterations cut by the pair budget end at other ranks for a band than for the whole frame, so tiles
+        # retire (T < 2^-11) at other points: the band may differ by one level, never more
+        assert np.abs(band[32:112].astype(np.int32) - img[32:112].astype(np.int32)).max() <= 1
+    else:
+        assert np.array_equal(band[32:112], img[32:112])
+
+
+def test_render_occlusion_culling_skips_hidden_pairs(gsx_fresh, pkg, oracle, synth):
+    gsx = gsx_fresh
+    w, h = 240, 176
+    # many small opaque-ish splats in a tight cloud: the centre tiles saturate within the nearest few hundred
+    splats = oracle.raw_to_splat(synth.clustered_cloud(60000, seed=8, n_clusters=3, sigma=0.3, frac=0.95, centre_extent=0.5, scale_mul=4.0))
+    view, proj, cam = camera(oracle, w, h, steps=2, distance=2.5)
+    gsx.upload(splats)
+    gsx.sort(cam)
+    u = pkg.make_uniforms(proj, view)
+    gsx.set_option("chunk_first", 1 << 30)
+    one = gsx.render(u, w, h); p_one = gsx.timings()["tile_pairs"]; i_one = gsx.timings()["render_iters"]
+    gsx.set_option("chunk_first", 512); gsx.set_option("chunk_growth", 2)
+    many = gsx.render(u, w, h); p_many = gsx.timings()["tile_pairs"]; i_many = gsx.timings()["render_iters"]
+    assert p_many < 0.6 * p_one, (p_many, p_one, i_many, i_one)
+    err = np.abs(one.astype(np.int32) - many.astype(np.int32))
+    assert err.max() <= 1                                          # only the saturation cut-off (T < 2^-11) may differ
+
+
+def test_set_option_rejects_unknown(gsx_fresh, pkg):
+    gsx = gsx_fresh
+    with pytest.raises(pkg.GsxError):
+        gsx.set_option("no_such_knob", 1)
+    with pytest.raises(pkg.GsxError):
+        gsx.set_option("chunk_growth", 1)
