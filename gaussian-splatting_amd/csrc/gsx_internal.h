@@ -64,14 +64,14 @@ struct GsxDevFlags {
     uint32_t pad[3];
 };
 
-// Projected splat record (48 B), written by k_project in ORIGINAL splat order.
+// Projected splat record (32 B), written by k_project in ORIGINAL splat order (the colour is not
+// copied: the rasterizer reads it from color4 directly).
 // Screen position of quad corner q in [-1,1]^2 is c + q.x*A + q.y*B (pixels);
 // m = cutOff * inverse([A B]) maps a pixel offset to the fragment's uv.
 struct GsxProj {
     float cx, cy;             // centre in pixels
     float ex, ey;             // half extents of the quad's pixel bbox (|A|+|B| per axis); ex < 0 = culled
     float m00, m01, m10, m11; // u = m00*dx + m01*dy, v = m10*dx + m11*dy
-    float r, g, b, a;
 };
 
 struct gsx_ctx {

@@ -8,7 +8,7 @@
 // (renderer.cpp:162-164).
 //
 // Design: vs_main runs ONCE per splat (the reference runs it 4x, once per quad
-// vertex) in original splat order with coalesced SoA loads and leaves a 48-B
+// vertex) in original splat order with coalesced SoA loads and leaves a 32-B
 // screen-space record.  Because every quad is a view-plane-parallel
 // parallelogram at constant clip w, uv is an affine function of the pixel
 // position, so coverage + uv come from one 2x2 inverse instead of triangle
@@ -58,12 +58,12 @@ __device__ __forceinline__ bool gsx_tile_bbox(float4 c, const GsxViewParams& vp,
 // K3: per-splat projection.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_project(const float4* __restrict__ pos4, const float4* __restrict__ covA,
-                                                 const float4* __restrict__ covB, const float4* __restrict__ color4,
+                                                 const float4* __restrict__ covB,
                                                  uint32_t n, GsxViewParams vp, GsxProj* __restrict__ out,
                                                  uint32_t* __restrict__ tbox) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const float4 p = pos4[i], ca = covA[i], cb = covB[i], col = color4[i];
+    const float4 p = pos4[i], ca = covA[i], cb = covB[i];
     const float* W = vp.wt;  // column-major 4x4; W[c*4+r]
     // s_center = wt * sm[3]  (wgsl:53)
     float ctr[4];
@@ -120,7 +120,6 @@ __global__ __launch_bounds__(256) void k_project(const float4* __restrict__ pos4
     const float idd = vp.cut / dd;
     o.m00 = by * idd; o.m01 = -bx * idd;
     o.m10 = -ay * idd; o.m11 = ax * idd;
-    o.r = col.x; o.g = col.y; o.b = col.z; o.a = col.w;
     // clip volume 0 <= z <= w (WebGPU), w > 0; non-finite vertices drop the primitive
     bool ok = (clip_w > 0.0f) && (clip_z >= 0.0f) && (clip_z <= clip_w);
     const float chk = cx + cy + o.ex + o.ey + o.m00 + o.m01 + o.m10 + o.m11;
@@ -133,11 +132,10 @@ __global__ __launch_bounds__(256) void k_project(const float4* __restrict__ pos4
              (yy0 <= static_cast<float>(vp.y1) - 1.0f);
     }
     if (!ok) o.ex = -1.0f;
-    // 48-B record as three 16-B stores
+    // 32-B record as two 16-B stores
     float4* dst = reinterpret_cast<float4*>(out + i);
     dst[0] = make_float4(o.cx, o.cy, o.ex, o.ey);
     dst[1] = make_float4(o.m00, o.m01, o.m10, o.m11);
-    dst[2] = make_float4(o.r, o.g, o.b, o.a);
     // 4-byte tile box for the binner (tx0 | ty0<<8 | tx1<<16 | ty1<<24; tx0 > tx1 = culled)
     uint32_t tx0, tx1, ty0, ty1, tb = GSX_TBOX_NONE;
     if (gsx_tile_bbox(make_float4(o.cx, o.cy, o.ex, o.ey), vp, tx0, tx1, ty0, ty1)) tb = tx0 | (ty0 << 8) | (tx1 << 16) | (ty1 << 24);
@@ -408,7 +406,7 @@ __global__ __launch_bounds__(256) void k_tile_ranges(const uint16_t* __restrict_
 // ---------------------------------------------------------------------------
 // K5: tile rasterizer.  One 256-thread workgroup per 16x16 tile, each wave an
 // 8x8 pixel quadrant; the tile's pair list of this iteration is staged through
-// LDS in batches (one 48-B gather per thread) and every thread walks the batch,
+// LDS in batches (a 32-B record and a 16-B colour gather per thread) and every thread walks the batch,
 // near -> far, on top of the accumulators the previous iterations left.
 // ---------------------------------------------------------------------------
 #define GSX_RASTER_BATCH 256
@@ -446,8 +444,8 @@ __device__ __forceinline__ uint32_t gsx_bayer(uint32_t x, uint32_t y, uint32_t b
 
 template <int MODE /*0 blend, 1 threshold (bayerSize 10), 2 bayer dither*/>
 __global__ __launch_bounds__(256) void k_raster(const uint32_t* __restrict__ tile_start, const uint32_t* __restrict__ pair_val,
-                                                const GsxProj* __restrict__ proj, const uint32_t* __restrict__ sorted,
-                                                GsxViewParams vp, uint32_t first, uint32_t* __restrict__ tile_state,
+                                                const GsxProj* __restrict__ proj, const float4* __restrict__ color4,
+                                                const uint32_t* __restrict__ sorted, GsxViewParams vp, uint32_t first, uint32_t* __restrict__ tile_state,
                                                 uint32_t* __restrict__ live_bits, float4* __restrict__ accum,
                                                 GsxFrameCtl* __restrict__ ctl, uint8_t* __restrict__ fb) {
     __shared__ float4 s_a[GSX_RASTER_BATCH];  // cx cy ex ey
@@ -490,7 +488,7 @@ __global__ __launch_bounds__(256) void k_raster(const uint32_t* __restrict__ til
             if (MODE == 2) { s_rank[tid] = pv; pv = sorted[pv]; }
             const float4* src = reinterpret_cast<const float4*>(proj + pv);
             a = src[0]; m = src[1];
-            s_a[tid] = a; s_m[tid] = m; s_c[tid] = src[2];
+            s_a[tid] = a; s_m[tid] = m; s_c[tid] = color4[pv];
         }
         // (computed by every lane and masked with `valid` explicitly: lanes past the batch must
         // contribute 0 bits to the ballots below)
@@ -674,13 +672,13 @@ static int launch_iteration(gsx_ctx* c, uint32_t iter, uint32_t window, bool fir
     if (c->profiling && iter < GSX_MAX_SCHED && !f.continuing) GSX_HIP(c, hipEventRecord(c->ev[EV_IT0 + 2 * iter], c->stream));
     const uint32_t fi = first ? 1u : 0u;
     if (f.mode == 0)
-        hipLaunchKernelGGL(k_raster<0>, dim3(f.n_tiles), dim3(256), 0, c->stream, c->tile_start, c->pair_val[cur], c->proj, sorted, vp,
+        hipLaunchKernelGGL(k_raster<0>, dim3(f.n_tiles), dim3(256), 0, c->stream, c->tile_start, c->pair_val[cur], c->proj, c->color4, sorted, vp,
                            fi, c->tile_state, c->live_bits, c->accum, c->ctl, c->fb);
     else if (f.mode == 1)
-        hipLaunchKernelGGL(k_raster<1>, dim3(f.n_tiles), dim3(256), 0, c->stream, c->tile_start, c->pair_val[cur], c->proj, sorted, vp,
+        hipLaunchKernelGGL(k_raster<1>, dim3(f.n_tiles), dim3(256), 0, c->stream, c->tile_start, c->pair_val[cur], c->proj, c->color4, sorted, vp,
                            fi, c->tile_state, c->live_bits, c->accum, c->ctl, c->fb);
     else
-        hipLaunchKernelGGL(k_raster<2>, dim3(f.n_tiles), dim3(256), 0, c->stream, c->tile_start, c->pair_val[cur], c->proj, sorted, vp,
+        hipLaunchKernelGGL(k_raster<2>, dim3(f.n_tiles), dim3(256), 0, c->stream, c->tile_start, c->pair_val[cur], c->proj, c->color4, sorted, vp,
                            fi, c->tile_state, c->live_bits, c->accum, c->ctl, c->fb);
     if (c->profiling && iter < GSX_MAX_SCHED && !f.continuing) GSX_HIP(c, hipEventRecord(c->ev[EV_IT0 + 2 * iter + 1], c->stream));
     return GSX_OK;
@@ -752,8 +750,8 @@ int gsx_launch_render(gsx_ctx* c, const gsx_uniforms* u, uint32_t w, uint32_t h,
     // K3
     if (c->profiling) GSX_HIP(c, hipEventRecord(c->ev[EV_PROJ0], c->stream));
     if (n > 0)
-        hipLaunchKernelGGL(k_project, dim3(gsx_div_up(n, 256)), dim3(256), 0, c->stream, c->pos4, c->covA, c->covB, c->color4,
-                           n, vp, c->proj, c->tbox);
+        hipLaunchKernelGGL(k_project, dim3(gsx_div_up(n, 256)), dim3(256), 0, c->stream, c->pos4, c->covA, c->covB, n, vp,
+                           c->proj, c->tbox);
     hipLaunchKernelGGL(k_frame_init, dim3(gsx_div_up(n_tiles, 256)), dim3(256), 0, c->stream, c->ctl, c->m_dev, c->live_bits,
                        c->tile_state, vp.tiles_x, vp.tiles_y);
     if (c->profiling) GSX_HIP(c, hipEventRecord(c->ev[EV_PROJ1], c->stream));
@@ -761,7 +759,7 @@ int gsx_launch_render(gsx_ctx* c, const gsx_uniforms* u, uint32_t w, uint32_t h,
     // K4 + K5: near -> far iterations with geometrically growing rank windows
     uint32_t n_iters = 0;
     uint64_t covered = 0;
-    uint64_t win = c->opt_chunk_first ? c->opt_chunk_first : (128u << 10);
+    uint64_t win = c->opt_chunk_first ? c->opt_chunk_first : (256u << 10);
     const uint64_t growth = c->opt_chunk_growth ? c->opt_chunk_growth : 4u;
     do {
         uint64_t wnd = win;

@@ -19,6 +19,7 @@ ap.add_argument("--w", type=int, default=1920)
 ap.add_argument("--h", type=int, default=1080)
 ap.add_argument("--iters", type=int, default=10)
 ap.add_argument("--sort-only", action="store_true")
+ap.add_argument("--opt", action="append", default=[], help="name=value for gsx_set_option")
 a = ap.parse_args()
 
 pkg = load_pkg()
@@ -35,6 +36,9 @@ view, proj, vp, cam = O.camera(world, 45.0, a.w / a.h)
 g = pkg.Gsx(0)
 g.upload(splats)
 g.set_profiling(True)
+for o in a.opt:
+    k, v = o.split('=')
+    g.set_option(k, int(v))
 u = pkg.make_uniforms(proj, view)
 for it in range(a.iters):
     t0 = time.perf_counter()
