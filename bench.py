@@ -6,16 +6,20 @@
 
 Workload (BASELINE.json configs[1]): 6M-splat synthetic clustered scene, one
 1920x1080 view per step.  A *step* is one complete frame of the hot path on
-data already resident in HBM: depth keys -> onesweep sort -> projection ->
-tile binning -> tile raster into a device RGBA8 framebuffer (no readback).
+data already resident in HBM: depth keys -> stable radix sort -> projection ->
+near-to-far iterations of (occlusion-aware tile binning -> pair sort -> tile raster)
+into a device RGBA8 framebuffer (no readback).
 At N > 1 the path shards by camera view over a replicated splat set (weak
 scaling: every rank renders its own view each step) and the finished frames are
 gathered to rank 0 with RCCL inside the timed region.
 
 Prints ONE JSON line on rank 0.  `value` = splats sorted (and drawn) per second
 over whole frames, aggregated over ranks; `fps_1080p` and the sort-only rate are
-reported next to it.  `roofline` describes the radix scatter kernel (k_radix_scatter);
-`cpu_baseline` times the CPU port of the reference's sortSplats on rank 0.
+reported next to it.  `roofline` describes the radix scatter kernel (k_radix_scatter<u32>): inside the
+timed region ONE of its launches per frame is bracketed by HIP events on the library's stream (the pass
+rotates frame by frame; bracketing every stage costs ~65 us per frame and is done on a few extra frames
+AFTER the timed region for `stage_ms`).  `cpu_baseline` times the CPU port of the reference's sortSplats
+on rank 0.
 """
 import argparse
 import importlib
@@ -123,7 +127,7 @@ def main():
 
     g = pkg.Gsx(local_rank)
     g.upload(splats)
-    g.set_profiling(True)
+    g.set_profiling(2)          # sampled: one k_radix_scatter launch per frame carries HIP events
     uniforms = [pkg.make_uniforms(v[1], v[0]) for v in my_views]
 
     fb_bytes = W * H * 4
@@ -153,15 +157,19 @@ def main():
         if dist is not None and not a.no_gather:
             gather()
     fence()
-    acc = {}
+    pass_ms, pass_n = {}, {}
+    pairs = iters = passes = 0
     t0 = time.perf_counter()
     for i in range(a.steps):
         step(i)
         if dist is not None and not a.no_gather:
             gather()
-        t = g.timings()        # HIP-event stage times of this frame (synchronises the frame, like a present)
-        for k, val in t.items():
-            acc[k] = acc.get(k, 0.0) + val
+        t = g.timings()        # waits for the frame (like a present) and reads the sampled scatter launch
+        if t["scatter_sample"]:
+            p = t["scatter_sample"] - 1
+            pass_ms[p] = pass_ms.get(p, 0.0) + t["scatter_ms"]
+            pass_n[p] = pass_n.get(p, 0) + 1
+        pairs += t["tile_pairs"]; iters += t["render_iters"]; passes += t["sort_passes"]
     fence()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -169,14 +177,33 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
+    # stage breakdown on a few extra frames with every stage bracketed (outside the timed region)
+    acc = {}
+    n_prof = 6
+    if rank == 0:
+        g.set_profiling(1)
+        for i in range(n_prof + 1):
+            step(i)
+            t = g.timings()
+            if i:                                  # first frame after switching levels is a warm-up
+                for k, val in t.items():
+                    acc[k] = acc.get(k, 0.0) + val
+
     if rank == 0:
         K = a.steps
         n = a.splats
-        passes = acc["sort_passes"] / K
-        pass_ms = acc["scatter_ms"] / K / max(passes, 1.0)     # HIP events around each k_radix_scatter launch
-        achieved = SCATTER_BYTES_PER_SPLAT * n / (pass_ms * 1e-3) / 1e9
-        keysort_ms = (acc["keygen_ms"] + acc["sort_ms"]) / K
-        sort_bytes = sort_bytes_per_splat(int(round(passes)))
+        passes_per_frame = passes / K
+        per_pass = {p: pass_ms[p] / pass_n[p] for p in pass_ms}          # mean launch duration of each radix pass
+        launch_ms = sum(per_pass.values()) / max(len(per_pass), 1)       # average k_radix_scatter<u32> launch
+        achieved = SCATTER_BYTES_PER_SPLAT * n / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
+        keysort_ms = (acc["keygen_ms"] + acc["sort_ms"]) / n_prof
+        sort_bytes = sort_bytes_per_splat(int(round(passes_per_frame)))
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "r1_scatter_traffic.json")     # PMC passes (tools/pmc_traffic.sh), committed
+        if os.path.exists(tf):
+            rec = json.load(open(tf))
+            if rec.get("splats") == n:
+                traffic = rec.get("hbm_bytes_per_launch")
         out = {
             "metric": "splats_sorted_per_s (whole 1080p frame: keys+sort+project+bin+raster)",
             "value": n * K * world / elapsed,
@@ -199,11 +226,14 @@ def main():
             "sort_only_bytes_per_splat": sort_bytes,
             "sort_only_hbm_frac": sort_bytes * n / (keysort_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "sort_only_hbm_frac_at_92B": 92 * n / (keysort_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-            "stage_ms": {k: acc[k] / K for k in ("select_ms", "keygen_ms", "sort_ms", "scatter_ms", "project_ms", "bin_ms", "raster_ms", "total_ms")},
-            "tile_pairs": int(acc["tile_pairs"] / K),
+            "stage_ms": {k: acc[k] / n_prof for k in ("select_ms", "keygen_ms", "sort_ms", "scatter_ms", "project_ms", "bin_ms", "raster_ms", "total_ms")},
+            "stage_ms_note": f"{n_prof} extra frames after the timed region with every stage bracketed by HIP events (adds ~65 us per frame)",
+            "tile_pairs": int(pairs / K),
+            "render_iters": iters / K,
             "roofline": {"kernel": "k_radix_scatter<u32> (one stable radix scatter pass of the depth sort)", "bound": "hbm", "achieved": achieved,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "avg_launch_ms": pass_ms, "launches_per_step": passes,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "avg_launch_ms": launch_ms, "per_pass_launch_ms": [per_pass[p] for p in sorted(per_pass)],
+                         "launches_per_step": passes_per_frame, "launches_timed": int(sum(pass_n.values())),
                          "algorithmic_bytes_per_launch": SCATTER_BYTES_PER_SPLAT * n},
         }
         if a.cpu_frames > 0:

@@ -51,7 +51,7 @@ class HcFlat(C.Structure):
 class Timings(C.Structure):
     _fields_ = [("select_ms", C.c_float), ("keygen_ms", C.c_float), ("sort_ms", C.c_float), ("scatter_ms", C.c_float), ("project_ms", C.c_float),
                 ("bin_ms", C.c_float), ("raster_ms", C.c_float), ("total_ms", C.c_float), ("sort_passes", C.c_uint32),
-                ("sort_launches", C.c_uint32), ("tile_pairs", C.c_uint64), ("render_iters", C.c_uint32), ("reserved", C.c_uint32)]
+                ("sort_launches", C.c_uint32), ("tile_pairs", C.c_uint64), ("render_iters", C.c_uint32), ("scatter_sample", C.c_uint32)]
 
 
 assert C.sizeof(Uniforms) == 224
@@ -212,7 +212,7 @@ class Gsx:
         self._chk(self.lib.gsx_sync(self.ctx))
 
     def set_profiling(self, on=True):
-        self._chk(self.lib.gsx_set_profiling(self.ctx, C.c_int(1 if on else 0)))
+        self._chk(self.lib.gsx_set_profiling(self.ctx, C.c_int(int(on))))   # 0 off, 1/True all stages, 2 sampled
 
     def set_option(self, name, value):
         """Tuning knob of the frame loop (include/gsx.h gsx_set_option): pair_budget, chunk_first, chunk_growth."""

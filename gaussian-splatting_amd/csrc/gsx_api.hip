@@ -166,7 +166,9 @@ int gsx_set_option(gsx_ctx* c, const char* name, uint64_t value) {
 
 int gsx_set_profiling(gsx_ctx* c, int enabled) {
     if (!c) return GSX_E_INVALID;
-    c->profiling = enabled != 0;
+    if (enabled < 0 || enabled > 2) return GSX_E_INVALID;
+    c->prof_level = enabled;
+    c->profiling = enabled == 1;
     return GSX_OK;
 }
 
@@ -197,6 +199,11 @@ int gsx_get_timings(gsx_ctx* c, gsx_timings* out) {
             }
         }
         t.total_ms = t.select_ms + t.keygen_ms + t.sort_ms + t.project_ms + t.bin_ms + t.raster_ms;
+    }
+    t.scatter_sample = 0;
+    if (c->prof_level == 2 && c->sorted_valid && c->sampled_pass >= 0) {
+        t.scatter_ms = ev_ms(c, EV_X0 + 2 * c->sampled_pass, EV_X0 + 2 * c->sampled_pass + 1);
+        t.scatter_sample = static_cast<uint32_t>(c->sampled_pass) + 1u;
     }
     if (c->sorted_valid) {
         t.sort_passes = c->sort_passes;

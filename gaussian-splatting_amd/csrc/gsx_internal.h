@@ -78,7 +78,10 @@ struct gsx_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     std::string err;
-    bool profiling = false;
+    bool profiling = false;            // level 1: events around every stage
+    int prof_level = 0;                // 0 off, 1 all stages, 2 sampled (one scatter launch per frame)
+    uint32_t prof_frame = 0;           // sorts launched (rotates the sampled pass)
+    int sampled_pass = -1;             // level 2: pass whose scatter launch carries events in the last sort
 
     // scene (SoA in HBM)
     uint64_t n = 0;

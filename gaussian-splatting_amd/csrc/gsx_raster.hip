@@ -269,44 +269,48 @@ __global__ __launch_bounds__(GSX_BIN_NT) void k_chunk_emit(const GsxFrameCtl* __
     static_assert(SUB == 64, "one rank per lane of wave 0");
     __shared__ uint32_t s_live[GSX_MAX_TILES_Y * GSX_LIVE_ROW_WORDS];
     __shared__ uint32_t s_off[SUB + 1], s_box[SUB], s_pay[SUB];
-    const uint32_t b = blockIdx.x / GSX_BIN_SUBS, sb = blockIdx.x % GSX_BIN_SUBS;
-    if (b >= ctl->n_blocks) return;
-    const uint32_t* so = sub_off + b * (GSX_BIN_SUBS + 1) + sb;
-    const uint32_t sub_base = so[0], sub_total = so[1] - so[0];
-    if (sub_total == 0u) return;
+    const uint32_t n_items = ctl->n_blocks * GSX_BIN_SUBS;       // sub-blocks of the blocks that fit the budget
+    if (blockIdx.x >= n_items) return;
     const uint32_t cur = ctl->cursor[iter], m = ctl->m;
     const uint32_t remaining = m - cur, win = window < remaining ? window : remaining;
     const uint32_t lw = (tiles_x + 31u) / 32u;
     for (uint32_t i = threadIdx.x; i < lw * tiles_y; i += GSX_BIN_NT) s_live[i] = live_bits[i];
-    __syncthreads();
-    if (threadIdx.x < 64) {
-        uint32_t box = 0, pay = 0;
-        const uint32_t cnt = gsx_rank_pairs<RANK_PAYLOAD>(b * GSX_BIN_TILE + sb * SUB + threadIdx.x, win, m - cur, sorted, tbox, s_live,
-                                                          lw, box, pay);
-        uint32_t incl = cnt;
+    // the grid is capped (a frame's last windows are mostly hidden): every workgroup strides over sub-blocks
+    for (uint32_t item = blockIdx.x; item < n_items; item += gridDim.x) {
+        const uint32_t b = item / GSX_BIN_SUBS, sb = item % GSX_BIN_SUBS;
+        const uint32_t* so = sub_off + b * (GSX_BIN_SUBS + 1) + sb;
+        const uint32_t sub_base = so[0], sub_total = so[1] - so[0];
+        if (sub_total == 0u) continue;                           // uniform
+        __syncthreads();                                         // s_live loaded; previous item's LDS reads done
+        if (threadIdx.x < 64) {
+            uint32_t box = 0, pay = 0;
+            const uint32_t cnt = gsx_rank_pairs<RANK_PAYLOAD>(b * GSX_BIN_TILE + sb * SUB + threadIdx.x, win, m - cur, sorted, tbox,
+                                                              s_live, lw, box, pay);
+            uint32_t incl = cnt;
 #pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const uint32_t t = __shfl_up(incl, off);
-            if (threadIdx.x >= static_cast<uint32_t>(off)) incl += t;
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t t = __shfl_up(incl, off);
+                if (threadIdx.x >= static_cast<uint32_t>(off)) incl += t;
+            }
+            s_off[threadIdx.x] = incl - cnt;
+            s_box[threadIdx.x] = box;
+            s_pay[threadIdx.x] = pay;
+            if (threadIdx.x == 63) s_off[64] = incl;
         }
-        s_off[threadIdx.x] = incl - cnt;
-        s_box[threadIdx.x] = box;
-        s_pay[threadIdx.x] = pay;
-        if (threadIdx.x == 63) s_off[64] = incl;
-    }
-    __syncthreads();
-    const uint32_t base = block_sums[b] + sub_base;   // block offsets were scanned by k_chunk_scan; fits the buffers by construction
-    for (uint32_t slot = threadIdx.x; slot < sub_total; slot += GSX_BIN_NT) {
-        uint32_t lo = 0;                              // last q with s_off[q] <= slot (skips empty ranks)
+        __syncthreads();
+        const uint32_t base = block_sums[b] + sub_base;   // block offsets were scanned by k_chunk_scan; fits the buffers by construction
+        for (uint32_t slot = threadIdx.x; slot < sub_total; slot += GSX_BIN_NT) {
+            uint32_t lo = 0;                              // last q with s_off[q] <= slot (skips empty ranks)
 #pragma unroll
-        for (uint32_t step = 32; step >= 1; step >>= 1)
-            if (s_off[lo + step] <= slot) lo += step;
-        const uint32_t local = slot - s_off[lo], bx = s_box[lo];
-        const uint32_t wx = bx >> 16;
-        const uint32_t dy = local / wx, dx = local - dy * wx;
-        const uint32_t tx = (bx & 0xFFu) + dx, ty = ((bx >> 8) & 0xFFu) + dy;
-        pair_key[base + slot] = static_cast<uint16_t>(ty * tiles_x + tx);
-        pair_val[base + slot] = s_pay[lo];
+            for (uint32_t step = 32; step >= 1; step >>= 1)
+                if (s_off[lo + step] <= slot) lo += step;
+            const uint32_t local = slot - s_off[lo], bx = s_box[lo];
+            const uint32_t wx = bx >> 16;
+            const uint32_t dy = local / wx, dx = local - dy * wx;
+            const uint32_t tx = (bx & 0xFFu) + dx, ty = ((bx >> 8) & 0xFFu) + dy;
+            pair_key[base + slot] = static_cast<uint16_t>(ty * tiles_x + tx);
+            pair_val[base + slot] = s_pay[lo];
+        }
     }
 }
 
@@ -343,7 +347,9 @@ __global__ __launch_bounds__(1024) void k_chunk_scan(GsxFrameCtl* __restrict__ c
     __shared__ uint32_t s_fit, s_pairs;
     if (threadIdx.x == 0) { s_carry = 0ull; s_fit = 0u; s_pairs = 0u; }
     __syncthreads();
-    for (uint32_t b0 = 0; b0 < nb; b0 += 1024 * PER) {
+    const bool dead = ctl->live_tiles == 0u;         // every count block wrote 0: the window is consumed whole
+    if (dead && threadIdx.x == 0) s_fit = nb;
+    for (uint32_t b0 = 0; b0 < nb && !dead; b0 += 1024 * PER) {
         const unsigned long long carry = s_carry;
         if (carry > budget) break;                   // uniform: nothing behind this point fits
         uint32_t v[PER];
@@ -637,12 +643,13 @@ static int launch_iteration(gsx_ctx* c, uint32_t iter, uint32_t window, bool fir
         hipLaunchKernelGGL(k_chunk_count, dim3(nb), dim3(GSX_BIN_NT), 0, c->stream, c->ctl, iter, window, sorted, c->tbox,
                            c->live_bits, vp.tiles_x, vp.tiles_y, c->scan_block_sums, c->sub_off);
         hipLaunchKernelGGL(k_chunk_scan, dim3(1), dim3(1024), 0, c->stream, c->ctl, iter, window, nb, c->scan_block_sums, budget);
+        const uint32_t emit_grid = nb * GSX_BIN_SUBS < 8192u ? nb * GSX_BIN_SUBS : 8192u;
         if (f.mode == 2)
-            hipLaunchKernelGGL(k_chunk_emit<true>, dim3(nb * GSX_BIN_SUBS), dim3(GSX_BIN_NT), 0, c->stream, c->ctl, iter, window,
+            hipLaunchKernelGGL(k_chunk_emit<true>, dim3(emit_grid), dim3(GSX_BIN_NT), 0, c->stream, c->ctl, iter, window,
                                sorted, c->tbox, c->live_bits, vp.tiles_x, vp.tiles_y, c->scan_block_sums, c->sub_off,
                                c->pair_key[0], c->pair_val[0]);
         else
-            hipLaunchKernelGGL(k_chunk_emit<false>, dim3(nb * GSX_BIN_SUBS), dim3(GSX_BIN_NT), 0, c->stream, c->ctl, iter, window,
+            hipLaunchKernelGGL(k_chunk_emit<false>, dim3(emit_grid), dim3(GSX_BIN_NT), 0, c->stream, c->ctl, iter, window,
                                sorted, c->tbox, c->live_bits, vp.tiles_x, vp.tiles_y, c->scan_block_sums, c->sub_off,
                                c->pair_key[0], c->pair_val[0]);
     }

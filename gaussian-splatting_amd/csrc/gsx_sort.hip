@@ -214,11 +214,14 @@ int gsx_launch_sort(gsx_ctx* c) {
                            c->cam[1], c->cam[2], key_lo, key_span, plan.shift[0], plan.bits[0], c->keys[0], c->sort_ws, c->flags);
     if (c->profiling) GSX_HIP(c, hipEventRecord(c->ev[EV_KEY1], c->stream));
     uint32_t cur = 0;
+    c->sampled_pass = (c->prof_level == 2 && plan.n_passes > 0) ? static_cast<int>(c->prof_frame % static_cast<uint32_t>(plan.n_passes)) : -1;
+    ++c->prof_frame;
     for (int p = 0; p < plan.n_passes; ++p) {
         const bool first = p == 0;
         launch_pass<uint32_t, GSX_SORT_NT, GSX_SORT_IPT>(c, c->stream, g, c->keys[cur], first ? c->sel_idx : c->vals[cur], c->keys[cur ^ 1],
                                                           c->vals[cur ^ 1], c->m_dev, plan.shift[p], plan.bits[p], c->sort_ws,
-                                                          /*need_hist=*/!first, /*iota=*/first && c->sel_iota, c->profiling ? p : -1);
+                                                          /*need_hist=*/!first, /*iota=*/first && c->sel_iota,
+                                                          (c->profiling || c->sampled_pass == p) ? p : -1);
         cur ^= 1;
     }
     if (c->profiling) GSX_HIP(c, hipEventRecord(c->ev[EV_SORT1], c->stream));

@@ -88,7 +88,7 @@ typedef struct gsx_timings {
     uint32_t sort_launches; /* kernel launches inside sort_ms */
     uint64_t tile_pairs;    /* (tile, splat) pairs the binner emitted (after occlusion culling) */
     uint32_t render_iters;  /* near -> far iterations of the frame that emitted pairs */
-    uint32_t reserved;
+    uint32_t scatter_sample; /* profiling level 2: 1 + index of the radix pass whose scatter launch scatter_ms times; else 0 */
 } gsx_timings;
 
 /* ---- lifecycle (replaces Renderer::init device bring-up, renderer.cpp:3-100) ---- */
@@ -96,7 +96,10 @@ int gsx_create(int device, gsx_ctx** out);
 int gsx_destroy(gsx_ctx* ctx);
 const char* gsx_last_error(const gsx_ctx* ctx);
 int gsx_sync(gsx_ctx* ctx);
-/* 1 = record HIP events around every stage (gsx_get_timings). Default 0. */
+/* 0 = no events (default).  1 = HIP events around every stage and every radix scatter launch
+ * (gsx_get_timings fills all *_ms fields; the ~20 events cost tens of microseconds per frame).
+ * 2 = sampled: per frame only ONE k_radix_scatter launch of the depth sort is bracketed, the pass
+ * rotating frame by frame (scatter_ms = that launch, scatter_sample says which pass). */
 int gsx_set_profiling(gsx_ctx* ctx, int enabled);
 int gsx_get_timings(gsx_ctx* ctx, gsx_timings* out);
 /* Tuning knobs of the frame loop (no counterpart in the reference; 0 restores the default):

@@ -2,6 +2,7 @@
 // buffer sizes the sort works on, and the cost of back-to-back dependent launches.
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
 
@@ -18,8 +19,21 @@ __global__ __launch_bounds__(256) void k_read16(const float4* __restrict__ a, fl
 }
 __global__ void k_empty(int* p) { if (p && threadIdx.x == 9999) *p = 1; }
 
-int main() {
+int main(int argc, char** argv) {
     hipStream_t st; CK(hipStreamCreate(&st));
+    if (argc == 3) {
+        // calibration mode for PMC passes: `membw <MiB> <copy16|copy4>` = 5 launches of one kernel over <MiB> MiB
+        const size_t sz = (size_t)atoi(argv[1]) << 20;
+        float *a, *b; CK(hipMalloc(&a, sz)); CK(hipMalloc(&b, sz));
+        CK(hipMemset(a, 1, sz)); CK(hipMemset(b, 0, sz));
+        for (int it = 0; it < 5; ++it) {
+            if (argv[2][4] == '1') hipLaunchKernelGGL(k_copy16, dim3((int)((sz / 16 + 255) / 256)), dim3(256), 0, st, (const float4*)a, (float4*)b, sz / 16);
+            else hipLaunchKernelGGL(k_copy4, dim3((int)((sz / 4 + 255) / 256)), dim3(256), 0, st, a, b, sz / 4);
+        }
+        CK(hipStreamSynchronize(st));
+        printf("calibration: %zu bytes read + %zu bytes written per launch\n", sz, sz);
+        return 0;
+    }
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     const size_t maxb = 1ull << 30;
     float *a, *b; CK(hipMalloc(&a, maxb)); CK(hipMalloc(&b, maxb));

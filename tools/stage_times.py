@@ -19,6 +19,7 @@ ap.add_argument("--w", type=int, default=1920)
 ap.add_argument("--h", type=int, default=1080)
 ap.add_argument("--iters", type=int, default=10)
 ap.add_argument("--sort-only", action="store_true")
+ap.add_argument("--no-profiling", action="store_true")
 ap.add_argument("--opt", action="append", default=[], help="name=value for gsx_set_option")
 a = ap.parse_args()
 
@@ -35,7 +36,7 @@ world, _ = O.orbit_world(5.0)
 view, proj, vp, cam = O.camera(world, 45.0, a.w / a.h)
 g = pkg.Gsx(0)
 g.upload(splats)
-g.set_profiling(True)
+g.set_profiling(not a.no_profiling)
 for o in a.opt:
     k, v = o.split('=')
     g.set_option(k, int(v))
