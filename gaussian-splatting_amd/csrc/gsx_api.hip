@@ -126,7 +126,7 @@ int gsx_destroy(gsx_ctx* c) {
     dev_free(&c->sort_ws); dev_free(&c->aabb_dev); dev_free(&c->flags); dev_free(&c->pair_ws);
     dev_free(&c->proj); dev_free(&c->splat_ntiles); dev_free(&c->scan_block_sums);
     dev_free(&c->tile_start); dev_free(&c->pair_total_dev); dev_free(&c->fb);
-    dev_free(&c->tbox); dev_free(&c->sub_off); dev_free(&c->ctl); dev_free(&c->live_bits); dev_free(&c->tile_state); dev_free(&c->accum);
+    dev_free(&c->tbox); dev_free(&c->sub_off); dev_free(&c->rank_box); dev_free(&c->rank_pay); dev_free(&c->ctl); dev_free(&c->live_bits); dev_free(&c->tile_state); dev_free(&c->accum);
     if (c->ctl_host) (void)hipHostFree(c->ctl_host);
     if (c->frame_ev) (void)hipEventDestroy(c->frame_ev);
     if (c->host_word) (void)hipHostFree(c->host_word);

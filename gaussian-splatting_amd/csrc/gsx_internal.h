@@ -149,6 +149,9 @@ struct gsx_ctx {
     uint64_t pair_grown = 0;           // budget a frame had to grow to (kept for later frames)
     uint32_t* sub_off = nullptr;       // per count block: 17 in-block pair offsets (64-rank boundaries)
     uint64_t sub_off_cap = 0;
+    uint32_t* rank_box = nullptr;      // per rank of the iteration's window: packed tile box / splat id, left by
+    uint32_t* rank_pay = nullptr;      // k_chunk_count for k_chunk_emit
+    uint64_t rank_box_cap = 0, rank_pay_cap = 0;
     uint32_t* tbox = nullptr;          // per splat: packed tile box (capacity proj_cap)
     GsxFrameCtl* ctl = nullptr;
     GsxFrameCtl* ctl_host = nullptr;   // pinned copy read after the frame

@@ -199,8 +199,9 @@ __device__ __forceinline__ bool gsx_box_live(const uint32_t* s_live, uint32_t lw
     return false;
 }
 
-// Packed tile box of rank `local` (0 = nearest rank of the iteration) -> pair count, box, payload.
-template <bool RANK_PAYLOAD>
+// Rank `local` (0 = nearest rank of the iteration) -> pair count; box = tx0 | ty0<<8 | (w-1)<<16 | (h-1)<<24 of its
+// tile box (GSX_RBOX_NONE when the splat is culled or every tile of the box is retired), pay = splat id.
+#define GSX_RBOX_NONE 0xFFFFFFFFu   // not a valid box: tx0 + (w-1) <= 255 always
 __device__ __forceinline__ uint32_t gsx_rank_pairs(uint32_t local, uint32_t win, uint32_t hi, const uint32_t* __restrict__ sorted,
                                                    const uint32_t* __restrict__ tbox, const uint32_t* s_live, uint32_t lw,
                                                    uint32_t& box, uint32_t& pay) {
@@ -209,13 +210,9 @@ __device__ __forceinline__ uint32_t gsx_rank_pairs(uint32_t local, uint32_t win,
     const uint32_t idx = sorted[r];
     const uint32_t tb = tbox[idx];
     const uint32_t tx0 = tb & 0xFFu, ty0 = (tb >> 8) & 0xFFu, tx1 = (tb >> 16) & 0xFFu, ty1 = tb >> 24;
-#ifdef GSX_DBG_NOCULL
-    if (tx0 > tx1) return 0u;
-#else
     if (tx0 > tx1 || !gsx_box_live(s_live, lw, tx0, tx1, ty0, ty1)) return 0u;
-#endif
-    box = tx0 | (ty0 << 8) | ((tx1 - tx0 + 1u) << 16);
-    pay = RANK_PAYLOAD ? r : idx;
+    box = tx0 | (ty0 << 8) | ((tx1 - tx0) << 16) | ((ty1 - ty0) << 24);
+    pay = idx;
     return (tx1 - tx0 + 1u) * (ty1 - ty0 + 1u);
 }
 
@@ -225,7 +222,8 @@ __device__ __forceinline__ uint32_t gsx_rank_pairs(uint32_t local, uint32_t win,
 __global__ __launch_bounds__(GSX_BIN_NT) void k_chunk_count(const GsxFrameCtl* __restrict__ ctl, uint32_t iter, uint32_t window,
                                                             const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ tbox,
                                                             const uint32_t* __restrict__ live_bits, uint32_t tiles_x, uint32_t tiles_y,
-                                                            uint32_t* __restrict__ block_sums, uint32_t* __restrict__ sub_off) {
+                                                            uint32_t* __restrict__ block_sums, uint32_t* __restrict__ sub_off,
+                                                            uint32_t* __restrict__ rank_box, uint32_t* __restrict__ rank_pay) {
     __shared__ uint32_t s_tmp[GSX_BIN_NT / 64];
     __shared__ uint32_t s_live[GSX_MAX_TILES_Y * GSX_LIVE_ROW_WORDS];
     const uint32_t b = blockIdx.x;
@@ -241,11 +239,16 @@ __global__ __launch_bounds__(GSX_BIN_NT) void k_chunk_count(const GsxFrameCtl* _
     __syncthreads();
     uint32_t tot = 0;
     const uint32_t local0 = b * GSX_BIN_TILE + threadIdx.x * GSX_BIN_IPT;
+    uint32_t rb[GSX_BIN_IPT], rp[GSX_BIN_IPT];
 #pragma unroll
     for (int j = 0; j < GSX_BIN_IPT; ++j) {
-        uint32_t box, pay;
-        tot += gsx_rank_pairs<false>(local0 + j, win, m - cur, sorted, tbox, s_live, lw, box, pay);
+        rb[j] = GSX_RBOX_NONE; rp[j] = 0u;
+        tot += gsx_rank_pairs(local0 + j, win, m - cur, sorted, tbox, s_live, lw, rb[j], rp[j]);
     }
+    // what k_chunk_emit needs per rank, in rank order (so it never repeats the gathers above)
+    static_assert(GSX_BIN_IPT == 4, "one 16-byte store per thread");
+    reinterpret_cast<uint4*>(rank_box)[local0 / 4] = make_uint4(rb[0], rb[1], rb[2], rb[3]);
+    reinterpret_cast<uint4*>(rank_pay)[local0 / 4] = make_uint4(rp[0], rp[1], rp[2], rp[3]);
     uint32_t block_total;
     const uint32_t excl = gsx_block_excl_scan<GSX_BIN_NT>(tot, s_tmp, &block_total);
     constexpr uint32_t TPS = GSX_BIN_NT / GSX_BIN_SUBS;          // threads per 64-rank sub-block
@@ -256,60 +259,61 @@ __global__ __launch_bounds__(GSX_BIN_NT) void k_chunk_count(const GsxFrameCtl* _
     }
 }
 
-// K4b.  One workgroup per 64-rank sub-block of the blocks that fit the budget: its pairs go to
-// [block offset + sub offset, ...) in near -> far order.  The workgroup writes them cooperatively
-// (coalesced stores); every slot finds its rank by binary search in the 65 offsets held in LDS.
+// K4b.  One WAVE per 64-rank sub-block of the blocks that fit the budget: its pairs go to
+// [block offset + sub offset, ...) in near -> far order.  The wave reads what k_chunk_count left per rank,
+// scans the 64 counts, and writes the pairs cooperatively (coalesced stores; every slot finds its rank by
+// binary search in the 65 offsets held in the wave's own LDS slice).  No workgroup barrier anywhere.
 template <bool RANK_PAYLOAD>
-__global__ __launch_bounds__(GSX_BIN_NT) void k_chunk_emit(const GsxFrameCtl* __restrict__ ctl, uint32_t iter, uint32_t window,
-                                                           const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ tbox,
-                                                           const uint32_t* __restrict__ live_bits, uint32_t tiles_x, uint32_t tiles_y,
+__global__ __launch_bounds__(GSX_BIN_NT) void k_chunk_emit(const GsxFrameCtl* __restrict__ ctl, uint32_t iter, uint32_t tiles_x,
                                                            const uint32_t* __restrict__ block_sums, const uint32_t* __restrict__ sub_off,
+                                                           const uint32_t* __restrict__ rank_box, const uint32_t* __restrict__ rank_pay,
                                                            uint16_t* __restrict__ pair_key, uint32_t* __restrict__ pair_val) {
     constexpr uint32_t SUB = GSX_BIN_TILE / GSX_BIN_SUBS;        // 64 ranks
-    static_assert(SUB == 64, "one rank per lane of wave 0");
-    __shared__ uint32_t s_live[GSX_MAX_TILES_Y * GSX_LIVE_ROW_WORDS];
-    __shared__ uint32_t s_off[SUB + 1], s_box[SUB], s_pay[SUB];
+    constexpr uint32_t NW = GSX_BIN_NT / 64;
+    static_assert(SUB == 64, "one rank per lane");
+    __shared__ uint32_t s_off[NW][SUB + 1], s_box[NW][SUB], s_pay[NW][SUB];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t n_items = ctl->n_blocks * GSX_BIN_SUBS;       // sub-blocks of the blocks that fit the budget
-    if (blockIdx.x >= n_items) return;
-    const uint32_t cur = ctl->cursor[iter], m = ctl->m;
-    const uint32_t remaining = m - cur, win = window < remaining ? window : remaining;
-    const uint32_t lw = (tiles_x + 31u) / 32u;
-    for (uint32_t i = threadIdx.x; i < lw * tiles_y; i += GSX_BIN_NT) s_live[i] = live_bits[i];
-    // the grid is capped (a frame's last windows are mostly hidden): every workgroup strides over sub-blocks
-    for (uint32_t item = blockIdx.x; item < n_items; item += gridDim.x) {
+    const uint32_t hi = ctl->m - ctl->cursor[iter];
+    uint32_t* off = s_off[wave];
+    uint32_t* sbx = s_box[wave];
+    uint32_t* spy = s_pay[wave];
+    // the grid is capped (a frame's last windows are mostly hidden): every wave strides over sub-blocks
+    for (uint32_t item = blockIdx.x * NW + wave; item < n_items; item += gridDim.x * NW) {
         const uint32_t b = item / GSX_BIN_SUBS, sb = item % GSX_BIN_SUBS;
         const uint32_t* so = sub_off + b * (GSX_BIN_SUBS + 1) + sb;
         const uint32_t sub_base = so[0], sub_total = so[1] - so[0];
-        if (sub_total == 0u) continue;                           // uniform
-        __syncthreads();                                         // s_live loaded; previous item's LDS reads done
-        if (threadIdx.x < 64) {
-            uint32_t box = 0, pay = 0;
-            const uint32_t cnt = gsx_rank_pairs<RANK_PAYLOAD>(b * GSX_BIN_TILE + sb * SUB + threadIdx.x, win, m - cur, sorted, tbox,
-                                                              s_live, lw, box, pay);
-            uint32_t incl = cnt;
+        if (sub_total == 0u) continue;                           // wave-uniform
+        const uint32_t local = b * GSX_BIN_TILE + sb * SUB + lane;
+        const uint32_t box = rank_box[local];
+        const uint32_t pay = RANK_PAYLOAD ? (hi - 1u - local) : rank_pay[local];
+        const uint32_t cnt = box == GSX_RBOX_NONE ? 0u : (((box >> 16) & 0xFFu) + 1u) * ((box >> 24) + 1u);
+        uint32_t incl = cnt;
 #pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const uint32_t t = __shfl_up(incl, off);
-                if (threadIdx.x >= static_cast<uint32_t>(off)) incl += t;
-            }
-            s_off[threadIdx.x] = incl - cnt;
-            s_box[threadIdx.x] = box;
-            s_pay[threadIdx.x] = pay;
-            if (threadIdx.x == 63) s_off[64] = incl;
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t t = __shfl_up(incl, o);
+            if (lane >= static_cast<uint32_t>(o)) incl += t;
         }
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier();                         // previous item's LDS reads are done (same wave, in order)
+        off[lane] = incl - cnt;
+        sbx[lane] = box;
+        spy[lane] = pay;
+        if (lane == 63) off[64] = incl;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         const uint32_t base = block_sums[b] + sub_base;   // block offsets were scanned by k_chunk_scan; fits the buffers by construction
-        for (uint32_t slot = threadIdx.x; slot < sub_total; slot += GSX_BIN_NT) {
-            uint32_t lo = 0;                              // last q with s_off[q] <= slot (skips empty ranks)
+        for (uint32_t slot = lane; slot < sub_total; slot += 64) {
+            uint32_t lo = 0;                              // last q with off[q] <= slot (skips empty ranks)
 #pragma unroll
             for (uint32_t step = 32; step >= 1; step >>= 1)
-                if (s_off[lo + step] <= slot) lo += step;
-            const uint32_t local = slot - s_off[lo], bx = s_box[lo];
-            const uint32_t wx = bx >> 16;
-            const uint32_t dy = local / wx, dx = local - dy * wx;
+                if (off[lo + step] <= slot) lo += step;
+            const uint32_t rel = slot - off[lo], bx = sbx[lo];
+            const uint32_t wx = ((bx >> 16) & 0xFFu) + 1u;
+            const uint32_t dy = rel / wx, dx = rel - dy * wx;
             const uint32_t tx = (bx & 0xFFu) + dx, ty = ((bx >> 8) & 0xFFu) + dy;
             pair_key[base + slot] = static_cast<uint16_t>(ty * tiles_x + tx);
-            pair_val[base + slot] = s_pay[lo];
+            pair_val[base + slot] = spy[lo];
         }
     }
 }
@@ -641,17 +645,16 @@ static int launch_iteration(gsx_ctx* c, uint32_t iter, uint32_t window, bool fir
     const uint32_t budget = static_cast<uint32_t>(c->pair_cap);
     if (nb > 0) {
         hipLaunchKernelGGL(k_chunk_count, dim3(nb), dim3(GSX_BIN_NT), 0, c->stream, c->ctl, iter, window, sorted, c->tbox,
-                           c->live_bits, vp.tiles_x, vp.tiles_y, c->scan_block_sums, c->sub_off);
+                           c->live_bits, vp.tiles_x, vp.tiles_y, c->scan_block_sums, c->sub_off, c->rank_box, c->rank_pay);
         hipLaunchKernelGGL(k_chunk_scan, dim3(1), dim3(1024), 0, c->stream, c->ctl, iter, window, nb, c->scan_block_sums, budget);
-        const uint32_t emit_grid = nb * GSX_BIN_SUBS < 8192u ? nb * GSX_BIN_SUBS : 8192u;
+        const uint32_t waves = nb * GSX_BIN_SUBS;                       // one per 64-rank sub-block, capped
+        const uint32_t emit_grid = gsx_div_up(waves, GSX_BIN_NT / 64) < 4096u ? gsx_div_up(waves, GSX_BIN_NT / 64) : 4096u;
         if (f.mode == 2)
-            hipLaunchKernelGGL(k_chunk_emit<true>, dim3(emit_grid), dim3(GSX_BIN_NT), 0, c->stream, c->ctl, iter, window,
-                               sorted, c->tbox, c->live_bits, vp.tiles_x, vp.tiles_y, c->scan_block_sums, c->sub_off,
-                               c->pair_key[0], c->pair_val[0]);
+            hipLaunchKernelGGL(k_chunk_emit<true>, dim3(emit_grid), dim3(GSX_BIN_NT), 0, c->stream, c->ctl, iter, vp.tiles_x,
+                               c->scan_block_sums, c->sub_off, c->rank_box, c->rank_pay, c->pair_key[0], c->pair_val[0]);
         else
-            hipLaunchKernelGGL(k_chunk_emit<false>, dim3(emit_grid), dim3(GSX_BIN_NT), 0, c->stream, c->ctl, iter, window,
-                               sorted, c->tbox, c->live_bits, vp.tiles_x, vp.tiles_y, c->scan_block_sums, c->sub_off,
-                               c->pair_key[0], c->pair_val[0]);
+            hipLaunchKernelGGL(k_chunk_emit<false>, dim3(emit_grid), dim3(GSX_BIN_NT), 0, c->stream, c->ctl, iter, vp.tiles_x,
+                               c->scan_block_sums, c->sub_off, c->rank_box, c->rank_pay, c->pair_key[0], c->pair_val[0]);
     }
     // stable sort of the iteration's pairs by tile id; the pair count stays on the device
     const uint32_t* count_ptr = &c->ctl->pairs;
@@ -737,6 +740,8 @@ int gsx_launch_render(gsx_ctx* c, const gsx_uniforms* u, uint32_t w, uint32_t h,
         const uint64_t nb_max = static_cast<uint64_t>(gsx_div_up(m_cap, GSX_BIN_TILE)) + 1;
         if ((rc = ensure(c, &c->scan_block_sums, &c->rank_cap, nb_max)) != GSX_OK) return rc;
         if ((rc = ensure(c, &c->sub_off, &c->sub_off_cap, nb_max * (GSX_BIN_SUBS + 1))) != GSX_OK) return rc;
+        if ((rc = ensure(c, &c->rank_box, &c->rank_box_cap, nb_max * GSX_BIN_TILE)) != GSX_OK) return rc;
+        if ((rc = ensure(c, &c->rank_pay, &c->rank_pay_cap, nb_max * GSX_BIN_TILE)) != GSX_OK) return rc;
     }
     // pair budget: what one iteration may emit (the device cuts iterations to fit it)
     uint64_t budget = c->opt_pair_budget;
