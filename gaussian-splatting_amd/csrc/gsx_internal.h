@@ -43,6 +43,9 @@ struct GsxFrameCtl {
     uint32_t max_pairs;    // largest iteration
     uint32_t iters_used;   // iterations that emitted pairs
     uint32_t stall;        // an iteration whose nearest block alone exceeds the budget
+#ifdef GSX_DEBUG_COUNT
+    unsigned long long dbg[4];
+#endif
 };
 
 // Host-side description of the frame in flight (for gsx_frame_finish).

@@ -478,6 +478,9 @@ __global__ __launch_bounds__(256) void k_raster(const uint32_t* __restrict__ til
     const float fx = static_cast<float>(px) + 0.5f, fy = static_cast<float>(py) + 0.5f;
     const bool inside = (px < static_cast<uint32_t>(vp.width)) && (py >= vp.y0) && (py < vp.y1);
 
+#ifdef GSX_DEBUG_COUNT
+    unsigned long long dbg_shaded = 0, dbg_hits = 0, dbg_useful = 0;
+#endif
     float T = inside ? 1.0f : 0.0f, cr = 0.0f, cg = 0.0f, cb = 0.0f;
     float4* acc = accum + static_cast<uint64_t>(tile) * (GSX_TILE_W * GSX_TILE_H) + tid;
     if (state == 1u) { const float4 a = *acc; cr = a.x; cg = a.y; cb = a.z; T = a.w; }
@@ -539,6 +542,11 @@ __global__ __launch_bounds__(256) void k_raster(const uint32_t* __restrict__ til
                     const float4 m = s_m[j];
                     const float dx = fx - a.x, dy = fy - a.y;
                     const float u = m.x * dx + m.y * dy, v = m.z * dx + m.w * dy;
+#ifdef GSX_DEBUG_COUNT
+                    ++dbg_shaded;
+                    dbg_hits += __popcll(__builtin_amdgcn_ballot_w64(fabsf(u) <= vp.cut && fabsf(v) <= vp.cut));
+                    dbg_useful += __popcll(__builtin_amdgcn_ballot_w64(fabsf(u) <= vp.cut && fabsf(v) <= vp.cut && T >= GSX_T_EPS));
+#endif
                     if (fabsf(u) <= vp.cut && fabsf(v) <= vp.cut) {
                         const float4 c = s_c[j];
                         float alpha = c.w * __expf(-0.5f * (u * u + v * v));
@@ -560,6 +568,12 @@ __global__ __launch_bounds__(256) void k_raster(const uint32_t* __restrict__ til
         __syncthreads();
         if (!s_live[0]) break;  // every pixel of the tile is saturated
     }
+#ifdef GSX_DEBUG_COUNT
+    if (lane == 0) {
+        atomicAdd(&ctl->dbg[0], dbg_shaded); atomicAdd(&ctl->dbg[1], dbg_hits); atomicAdd(&ctl->dbg[2], dbg_useful);
+        atomicAdd(&ctl->dbg[3], (end - begin));
+    }
+#endif
     // retire the tile or park its accumulators for the next iteration
     __syncthreads();
     if (tid == 0) s_live[1] = 0;
@@ -576,7 +590,6 @@ __global__ __launch_bounds__(256) void k_raster(const uint32_t* __restrict__ til
         atomicSub(&ctl->live_tiles, 1u);
     }
 #ifdef GSX_DEBUG_COUNT
-    if (!s_live[1]) *acc = make_float4(cr, cg, cb, T);
 #endif
     // the framebuffer always holds the composite of everything drawn so far over the clear colour
     if (inside) {
@@ -759,7 +772,7 @@ int gsx_launch_render(gsx_ctx* c, const gsx_uniforms* u, uint32_t w, uint32_t h,
     f.n_tiles = n_tiles;
     f.continuing = false;
 
-    // K3
+    // K3 (measured: running it on a second stream next to the depth sort gains nothing, the sort fills the chip)
     if (c->profiling) GSX_HIP(c, hipEventRecord(c->ev[EV_PROJ0], c->stream));
     if (n > 0)
         hipLaunchKernelGGL(k_project, dim3(gsx_div_up(n, 256)), dim3(256), 0, c->stream, c->pos4, c->covA, c->covB, n, vp,
