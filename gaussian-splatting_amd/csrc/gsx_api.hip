@@ -157,6 +157,8 @@ int gsx_set_option(gsx_ctx* c, const char* name, uint64_t value) {
     } else if (!std::strcmp(name, "chunk_growth")) {
         if (value == 1 || value > 1024) { c->err = "chunk_growth must be 0 or 2..1024"; return GSX_E_INVALID; }
         c->opt_chunk_growth = value;
+    } else if (!std::strcmp(name, "no_history")) {
+        c->opt_no_history = value ? 1 : 0;
     } else {
         c->err = std::string("unknown option: ") + name;
         return GSX_E_INVALID;

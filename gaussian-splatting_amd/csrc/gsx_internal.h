@@ -43,6 +43,7 @@ struct GsxFrameCtl {
     uint32_t max_pairs;    // largest iteration
     uint32_t iters_used;   // iterations that emitted pairs
     uint32_t stall;        // an iteration whose nearest block alone exceeds the budget
+    uint32_t dead_at;      // 1 + cursor at which an iteration first found every tile retired (0 = never)
 #ifdef GSX_DEBUG_COUNT
     unsigned long long dbg[4];
 #endif
@@ -54,6 +55,7 @@ struct GsxFrameState {
     int mode = 0;
     uint32_t n_tiles = 0;
     uint32_t n_iters = 0;
+    uint32_t need_base = 0;   // ranks the schedule was derived from (before the margin)
     bool continuing = false;
 };
 
@@ -164,10 +166,13 @@ struct gsx_ctx {
     float4* accum = nullptr;           // per tile x 256 pixels: (r, g, b, transmittance)
     uint64_t accum_cap = 0;
     GsxFrameState frame;
+    // ranks (from the near end) earlier frames needed before every tile was retired; ~0u = the whole selection
+    uint32_t need_hist[8] = {};
+    uint32_t need_pos = 0;             // frames recorded so far (ring position = need_pos % 8)
     hipEvent_t frame_ev = nullptr;
     bool frame_pending = false;
     // tuning (gsx_set_option); 0 = automatic
-    uint64_t opt_pair_budget = 0, opt_chunk_first = 0, opt_chunk_growth = 0;
+    uint64_t opt_pair_budget = 0, opt_chunk_first = 0, opt_chunk_growth = 0, opt_no_history = 0;
 
     // timing
     hipEvent_t ev[40] = {};

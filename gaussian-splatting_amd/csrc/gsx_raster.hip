@@ -395,6 +395,7 @@ __global__ __launch_bounds__(1024) void k_chunk_scan(GsxFrameCtl* __restrict__ c
         if (s_pairs > ctl->max_pairs) ctl->max_pairs = s_pairs;
         if (s_pairs) ctl->iters_used += 1u;
         if (take == 0u && win != 0u) ctl->stall = 1u;   // the nearest block alone exceeds the budget
+        if (dead && ctl->dead_at == 0u) ctl->dead_at = cur + 1u;
     }
 }
 
@@ -781,19 +782,27 @@ int gsx_launch_render(gsx_ctx* c, const gsx_uniforms* u, uint32_t w, uint32_t h,
                        c->tile_state, vp.tiles_x, vp.tiles_y);
     if (c->profiling) GSX_HIP(c, hipEventRecord(c->ev[EV_PROJ1], c->stream));
 
-    // K4 + K5: near -> far iterations with geometrically growing rank windows
+    // K4 + K5: near -> far iterations with geometrically growing rank windows.  Only as many ranks are scheduled
+    // as recent frames needed before every tile was retired (+25 %): what lies behind is hidden anyway, and if this
+    // frame does need more, gsx_frame_finish runs the rest (correct, just not pre-queued).
+    uint64_t need = c->need_pos ? 0 : ~0u;
+    for (uint32_t k = 0; k < 8 && k < c->need_pos; ++k) need = c->need_hist[k] > need ? c->need_hist[k] : need;
+    if (need > m_cap) need = m_cap;
+    c->frame.need_base = static_cast<uint32_t>(need);
+    need = need + need / 4 + 65536;
+    if (need > m_cap || c->opt_no_history) need = m_cap;
     uint32_t n_iters = 0;
     uint64_t covered = 0;
     uint64_t win = c->opt_chunk_first ? c->opt_chunk_first : (256u << 10);
     const uint64_t growth = c->opt_chunk_growth ? c->opt_chunk_growth : 4u;
     do {
         uint64_t wnd = win;
-        if (n_iters + 1 == GSX_MAX_SCHED || covered + wnd + wnd / 2 >= m_cap) wnd = m_cap - covered;   // last one takes the rest
+        if (n_iters + 1 == GSX_MAX_SCHED || covered + wnd + wnd / 2 >= need) wnd = need - covered;   // last one takes the rest
         if ((rc = launch_iteration(c, n_iters, static_cast<uint32_t>(wnd), n_iters == 0)) != GSX_OK) return rc;
         covered += wnd;
         win *= growth;
         ++n_iters;
-    } while (covered < m_cap);
+    } while (covered < need);
     f.n_iters = n_iters;
     GSX_HIP(c, hipMemcpyAsync(c->ctl_host, c->ctl, sizeof(GsxFrameCtl), hipMemcpyDeviceToHost, c->stream));
     GSX_HIP(c, hipEventRecord(c->frame_ev, c->stream));
@@ -838,6 +847,15 @@ int gsx_frame_finish(gsx_ctx* c) {
         GSX_HIP(c, hipMemcpyAsync(c->ctl_host, c->ctl, sizeof(GsxFrameCtl), hipMemcpyDeviceToHost, c->stream));
         GSX_HIP(c, hipStreamSynchronize(c->stream));
         last = 1;
+    }
+    {
+        // how deep this frame had to go: the cursor at which an iteration found every tile retired, else (all retired
+        // by the end of the queued iterations) what the schedule was based on, else everything
+        const GsxFrameCtl& h = *c->ctl_host;
+        uint32_t rec = ~0u;
+        if (h.dead_at) rec = h.dead_at - 1u;
+        else if (h.live_tiles == 0u) rec = h.cursor[last] < f.need_base ? h.cursor[last] : f.need_base;
+        c->need_hist[c->need_pos++ % 8u] = rec;
     }
     c->tim.tile_pairs = c->ctl_host->total_pairs;
     c->tim.render_iters = c->ctl_host->iters_used;

@@ -107,6 +107,8 @@ int gsx_get_timings(gsx_ctx* ctx, gsx_timings* out);
  *                   12 bytes per pair); the device cuts iterations to fit and a frame that needs
  *                   more simply runs more iterations
  *   "chunk_first"   ranks of the first (nearest) iteration;  "chunk_growth"  window growth factor
+ *   "no_history"    1 = always pre-queue iterations for the whole selection (default: only as many ranks as
+ *                   the last 8 frames needed before every tile was saturated, +25 %; the rest runs on demand)
  * Unknown name -> GSX_E_INVALID. */
 int gsx_set_option(gsx_ctx* ctx, const char* name, uint64_t value);
 
