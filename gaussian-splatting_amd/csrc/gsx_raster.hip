@@ -415,12 +415,13 @@ __global__ __launch_bounds__(256) void k_tile_ranges(const uint16_t* __restrict_
 }
 
 // ---------------------------------------------------------------------------
-// K5: tile rasterizer.  One 256-thread workgroup per 16x16 tile, each wave an
-// 8x8 pixel quadrant; the tile's pair list of this iteration is staged through
+// K5: tile rasterizer.  One 128-thread workgroup per 16x16 tile, each wave a
+// 16x8 half (two pixels per lane); the tile's pair list of this iteration is staged through
 // LDS in batches (a 32-B record and a 16-B colour gather per thread) and every thread walks the batch,
 // near -> far, on top of the accumulators the previous iterations left.
 // ---------------------------------------------------------------------------
-#define GSX_RASTER_BATCH 256
+#define GSX_RASTER_NT 128            // threads per tile: 2 waves x 64 lanes x 2 pixels
+#define GSX_RASTER_BATCH 128
 #define GSX_RASTER_CHECK 8           // a wave re-checks "all my pixels saturated" every this many shaded splats
 #ifndef GSX_T_EPS
 #define GSX_T_EPS (1.0f / 2048.0f)
@@ -453,17 +454,32 @@ __device__ __forceinline__ uint32_t gsx_bayer(uint32_t x, uint32_t y, uint32_t b
     return value;
 }
 
+typedef float gsx_f2 __attribute__((ext_vector_type(2)));   // two pixels of one lane: arithmetic lowers to v_pk_*_f32
+
+__device__ __forceinline__ uint32_t gsx_pack_rgba8(float r, float g, float b) {
+    const uint32_t r8 = static_cast<uint32_t>(fminf(fmaxf(r, 0.0f), 1.0f) * 255.0f + 0.5f);
+    const uint32_t g8 = static_cast<uint32_t>(fminf(fmaxf(g, 0.0f), 1.0f) * 255.0f + 0.5f);
+    const uint32_t b8 = static_cast<uint32_t>(fminf(fmaxf(b, 0.0f), 1.0f) * 255.0f + 0.5f);
+    return r8 | (g8 << 8) | (b8 << 16) | 0xFF000000u;
+}
+
+// One 128-thread workgroup per 16x16 tile.  Wave w owns the 16x8 half (rows 8w .. 8w+7); a lane owns the two
+// horizontally adjacent pixels (2*(lane&7), 2*(lane&7)+1) of row lane>>3, so that every arithmetic step of the
+// shading loop is one packed-f32 instruction for both pixels (measured: the loop is VALU-bound).
 template <int MODE /*0 blend, 1 threshold (bayerSize 10), 2 bayer dither*/>
-__global__ __launch_bounds__(256) void k_raster(const uint32_t* __restrict__ tile_start, const uint32_t* __restrict__ pair_val,
-                                                const GsxProj* __restrict__ proj, const float4* __restrict__ color4,
-                                                const uint32_t* __restrict__ sorted, GsxViewParams vp, uint32_t first, uint32_t* __restrict__ tile_state,
-                                                uint32_t* __restrict__ live_bits, float4* __restrict__ accum,
-                                                GsxFrameCtl* __restrict__ ctl, uint8_t* __restrict__ fb) {
+__global__ __launch_bounds__(GSX_RASTER_NT) void k_raster(const uint32_t* __restrict__ tile_start, const uint32_t* __restrict__ pair_val,
+                                                          const GsxProj* __restrict__ proj, const float4* __restrict__ color4,
+                                                          const uint32_t* __restrict__ sorted, GsxViewParams vp, uint32_t first,
+                                                          uint32_t* __restrict__ tile_state, uint32_t* __restrict__ live_bits,
+                                                          float4* __restrict__ accum, GsxFrameCtl* __restrict__ ctl,
+                                                          uint8_t* __restrict__ fb) {
+    constexpr uint32_t NW = GSX_RASTER_NT / 64;                   // 2 waves = 2 halves
+    static_assert(GSX_RASTER_BATCH == GSX_RASTER_NT, "one staged splat per thread");
     __shared__ float4 s_a[GSX_RASTER_BATCH];  // cx cy ex ey
     __shared__ float4 s_m[GSX_RASTER_BATCH];  // m00 m01 m10 m11
     __shared__ float4 s_c[GSX_RASTER_BATCH];  // r g b a
     __shared__ uint32_t s_rank[MODE == 2 ? GSX_RASTER_BATCH : 1];
-    __shared__ uint64_t s_mask[4][4];          // [quadrant][staging wave]: splats of the batch whose quad touches the quadrant
+    __shared__ uint64_t s_mask[NW][NW];        // [half][staging wave]: splats of the batch whose quad touches the half
     __shared__ int s_live[2];
     const uint32_t tile = blockIdx.x;
     const uint32_t state = tile_state[tile];           // 0 untouched, 1 accumulators valid, 2 retired
@@ -473,26 +489,29 @@ __global__ __launch_bounds__(256) void k_raster(const uint32_t* __restrict__ til
     const uint32_t ttx = tile % vp.tiles_x, tty = tile / vp.tiles_x;
     const uint32_t tx = ttx, ty = tty + vp.tile_y0;
     const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    // wave = 8x8 quadrant, lane = (lx, ly) inside it
-    const uint32_t qx = (wave & 1) * 8, qy = (wave >> 1) * 8;
-    const uint32_t px = tx * GSX_TILE_W + qx + (lane & 7), py = ty * GSX_TILE_H + qy + (lane >> 3);
-    const float fx = static_cast<float>(px) + 0.5f, fy = static_cast<float>(py) + 0.5f;
-    const bool inside = (px < static_cast<uint32_t>(vp.width)) && (py >= vp.y0) && (py < vp.y1);
-
+    const uint32_t px = tx * GSX_TILE_W + (lane & 7) * 2, py = ty * GSX_TILE_H + wave * 8 + (lane >> 3);
+    const gsx_f2 fx = {static_cast<float>(px) + 0.5f, static_cast<float>(px) + 1.5f};
+    const float fy = static_cast<float>(py) + 0.5f;
+    const bool row_in = (py >= vp.y0) && (py < vp.y1);
+    const bool in0 = row_in && (px < static_cast<uint32_t>(vp.width)), in1 = row_in && (px + 1 < static_cast<uint32_t>(vp.width));
 #ifdef GSX_DEBUG_COUNT
     unsigned long long dbg_shaded = 0, dbg_hits = 0, dbg_useful = 0;
 #endif
-    float T = inside ? 1.0f : 0.0f, cr = 0.0f, cg = 0.0f, cb = 0.0f;
-    float4* acc = accum + static_cast<uint64_t>(tile) * (GSX_TILE_W * GSX_TILE_H) + tid;
-    if (state == 1u) { const float4 a = *acc; cr = a.x; cg = a.y; cb = a.z; T = a.w; }
-    // pixel-centre rectangle of quadrant 0; quadrant q is offset by (8 * (q & 1), 8 * (q >> 1))
+    gsx_f2 T = {in0 ? 1.0f : 0.0f, in1 ? 1.0f : 0.0f}, cr = {0.0f, 0.0f}, cg = {0.0f, 0.0f}, cb = {0.0f, 0.0f};
+    float4* acc = accum + static_cast<uint64_t>(tile) * (GSX_TILE_W * GSX_TILE_H) + tid * 2;
+    if (state == 1u) {
+        const float4 a0 = acc[0], a1 = acc[1];
+        cr = gsx_f2{a0.x, a1.x}; cg = gsx_f2{a0.y, a1.y}; cb = gsx_f2{a0.z, a1.z}; T = gsx_f2{a0.w, a1.w};
+    }
+    const float cut = vp.cut;
+    // pixel-centre rectangle of half 0; half w is offset by 8 rows
     const float tx0f = static_cast<float>(tx * GSX_TILE_W) + 0.5f, ty0f = static_cast<float>(ty * GSX_TILE_H) + 0.5f;
     // near -> far: this iteration's list of the tile is already in that order
     for (uint32_t lo = begin; lo < end;) {
         const uint32_t nb = min(static_cast<uint32_t>(GSX_RASTER_BATCH), end - lo);
         __syncthreads();  // previous batch fully consumed
         if (tid == 0) s_live[0] = 0;
-        // stage: thread j gathers splat j of the batch and tests its quad against the four 8x8 quadrants
+        // stage: thread j gathers splat j of the batch and tests its quad against the two 16x8 halves
         // (separating axes: the pixel axes and the quad's u / v axes, with a rounding margin so that no
         // pixel the per-pixel test below would accept is ever dropped)
         const bool valid = tid < nb;
@@ -506,64 +525,71 @@ __global__ __launch_bounds__(256) void k_raster(const uint32_t* __restrict__ til
         }
         // (computed by every lane and masked with `valid` explicitly: lanes past the batch must
         // contribute 0 bits to the ballots below)
-        bool hit[4];
+        bool hit[NW];
         {
             const float amx = fabsf(m.x), amy = fabsf(m.y), amz = fabsf(m.z), amw = fabsf(m.w);
+            const float dxc = (tx0f + 7.5f) - a.x, adx = fabsf(dxc) + 7.5f;
+            const bool boxx = !(a.x + a.z < tx0f || a.x - a.z > tx0f + 15.0f);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float x0 = tx0f + static_cast<float>((q & 1) * 8), y0 = ty0f + static_cast<float>((q >> 1) * 8);
-                const bool box = !(a.x + a.z < x0 || a.x - a.z > x0 + 7.0f || a.y + a.w < y0 || a.y - a.w > y0 + 7.0f);
-                const float dxc = (x0 + 3.5f) - a.x, dyc = (y0 + 3.5f) - a.y;
-                const float adx = fabsf(dxc) + 3.5f, ady = fabsf(dyc) + 3.5f;
+            for (uint32_t q = 0; q < NW; ++q) {
+                const float y0 = ty0f + static_cast<float>(q * 8);
+                const bool box = boxx && !(a.y + a.w < y0 || a.y - a.w > y0 + 7.0f);
+                const float dyc = (y0 + 3.5f) - a.y, ady = fabsf(dyc) + 3.5f;
                 const float uc = m.x * dxc + m.y * dyc, vc = m.z * dxc + m.w * dyc;
-                const float ur = (amx + amy) * 3.5f + 1.0e-5f * (amx * adx + amy * ady) + 1.0e-6f;
-                const float vr = (amz + amw) * 3.5f + 1.0e-5f * (amz * adx + amw * ady) + 1.0e-6f;
-                hit[q] = valid && box && (fabsf(uc) - ur <= vp.cut) && (fabsf(vc) - vr <= vp.cut);
+                const float ur = amx * 7.5f + amy * 3.5f + 1.0e-5f * (amx * adx + amy * ady) + 1.0e-6f;
+                const float vr = amz * 7.5f + amw * 3.5f + 1.0e-5f * (amz * adx + amw * ady) + 1.0e-6f;
+                hit[q] = valid && box && (fabsf(uc) - ur <= cut) && (fabsf(vc) - vr <= cut);
             }
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (uint32_t q = 0; q < NW; ++q) {
             const uint64_t bal = __builtin_amdgcn_ballot_w64(hit[q]);
             if (lane == 0) s_mask[q][wave] = bal;
         }
         __syncthreads();
-        bool wave_live = __builtin_amdgcn_ballot_w64(T >= GSX_T_EPS) != 0;
-        for (uint32_t w = 0; w < 4 && wave_live; ++w) {
+        bool wave_live = __builtin_amdgcn_ballot_w64(T.x >= GSX_T_EPS || T.y >= GSX_T_EPS) != 0;
+        for (uint32_t w = 0; w < NW && wave_live; ++w) {
             const uint64_t mk = s_mask[wave][w];
             // (readfirstlane returns int: convert each half to u32 BEFORE widening, or bit 31 sign-extends)
             const uint32_t mk_lo = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(static_cast<uint32_t>(mk))));
             const uint32_t mk_hi = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(static_cast<uint32_t>(mk >> 32))));
             uint64_t mask = (static_cast<uint64_t>(mk_hi) << 32) | mk_lo;
             while (mask) {
-                if (__builtin_amdgcn_ballot_w64(T >= GSX_T_EPS) == 0) { wave_live = false; break; }   // all 64 pixels saturated
+                if (__builtin_amdgcn_ballot_w64(T.x >= GSX_T_EPS || T.y >= GSX_T_EPS) == 0) { wave_live = false; break; }   // all 128 pixels saturated
                 for (int k = 0; k < GSX_RASTER_CHECK && mask; ++k) {
                     const uint32_t j = w * 64u + static_cast<uint32_t>(__builtin_ctzll(mask));
                     mask &= mask - 1;
-                    const float4 a = s_a[j];
-                    const float4 m = s_m[j];
-                    const float dx = fx - a.x, dy = fy - a.y;
-                    const float u = m.x * dx + m.y * dy, v = m.z * dx + m.w * dy;
+                    const float4 sa = s_a[j];
+                    const float4 sm = s_m[j];
+                    const gsx_f2 dx = fx - sa.x;
+                    const float dy = fy - sa.y;
+                    const gsx_f2 u = sm.x * dx + sm.y * dy, v = sm.z * dx + sm.w * dy;
+                    const bool h0 = fabsf(u.x) <= cut && fabsf(v.x) <= cut, h1 = fabsf(u.y) <= cut && fabsf(v.y) <= cut;
 #ifdef GSX_DEBUG_COUNT
                     ++dbg_shaded;
-                    dbg_hits += __popcll(__builtin_amdgcn_ballot_w64(fabsf(u) <= vp.cut && fabsf(v) <= vp.cut));
-                    dbg_useful += __popcll(__builtin_amdgcn_ballot_w64(fabsf(u) <= vp.cut && fabsf(v) <= vp.cut && T >= GSX_T_EPS));
+                    dbg_hits += __popcll(__builtin_amdgcn_ballot_w64(h0)) + __popcll(__builtin_amdgcn_ballot_w64(h1));
+                    dbg_useful += __popcll(__builtin_amdgcn_ballot_w64(h0 && T.x >= GSX_T_EPS)) + __popcll(__builtin_amdgcn_ballot_w64(h1 && T.y >= GSX_T_EPS));
 #endif
-                    if (fabsf(u) <= vp.cut && fabsf(v) <= vp.cut) {
+                    if (h0 || h1) {
                         const float4 c = s_c[j];
-                        float alpha = c.w * __expf(-0.5f * (u * u + v * v));
-                        if (MODE == 1) alpha = (alpha > vp.bayer_scale) ? 1.0f : 0.0f;
+                        const gsx_f2 r2 = u * u + v * v;
+                        gsx_f2 alpha = {h0 ? c.w * __expf(-0.5f * r2.x) : 0.0f, h1 ? c.w * __expf(-0.5f * r2.y) : 0.0f};
+                        if (MODE == 1) { alpha.x = (alpha.x > vp.bayer_scale) ? 1.0f : 0.0f; alpha.y = (alpha.y > vp.bayer_scale) ? 1.0f : 0.0f; }
                         if (MODE == 2) {
-                            const float bv = static_cast<float>(gsx_bayer(px, py, vp.bayer_size, s_rank[j]));
-                            alpha = ((alpha * vp.bayer_scale) * static_cast<float>(vp.bayer_size * vp.bayer_size + 1u) < bv + 1.0f) ? 0.0f : 1.0f;
+                            const float lim = static_cast<float>(vp.bayer_size * vp.bayer_size + 1u);
+                            const float bv0 = static_cast<float>(gsx_bayer(px, py, vp.bayer_size, s_rank[j]));
+                            const float bv1 = static_cast<float>(gsx_bayer(px + 1, py, vp.bayer_size, s_rank[j]));
+                            alpha.x = (!h0 || (alpha.x * vp.bayer_scale) * lim < bv0 + 1.0f) ? 0.0f : 1.0f;
+                            alpha.y = (!h1 || (alpha.y * vp.bayer_scale) * lim < bv1 + 1.0f) ? 0.0f : 1.0f;
                         }
-                        const float wgt = T * alpha;
+                        const gsx_f2 wgt = T * alpha;
                         cr += wgt * c.x; cg += wgt * c.y; cb += wgt * c.z;
                         T -= wgt;  // T *= (1 - alpha)
                     }
                 }
             }
         }
-        wave_live = __builtin_amdgcn_ballot_w64(T >= GSX_T_EPS) != 0;
+        wave_live = __builtin_amdgcn_ballot_w64(T.x >= GSX_T_EPS || T.y >= GSX_T_EPS) != 0;
         if (lane == 0 && wave_live) s_live[0] = 1;
         lo += nb;
         __syncthreads();
@@ -579,28 +605,22 @@ __global__ __launch_bounds__(256) void k_raster(const uint32_t* __restrict__ til
     __syncthreads();
     if (tid == 0) s_live[1] = 0;
     __syncthreads();
-    const bool any_live = __builtin_amdgcn_ballot_w64(T >= GSX_T_EPS) != 0;   // every lane votes: keep it outside the lane-0 branch
+    const bool any_live = __builtin_amdgcn_ballot_w64(T.x >= GSX_T_EPS || T.y >= GSX_T_EPS) != 0;   // every lane votes: keep it outside the lane-0 branch
     if (lane == 0 && any_live) s_live[1] = 1;
     __syncthreads();
     if (s_live[1]) {
-        *acc = make_float4(cr, cg, cb, T);
+        acc[0] = make_float4(cr.x, cg.x, cb.x, T.x);
+        acc[1] = make_float4(cr.y, cg.y, cb.y, T.y);
         if (tid == 0) tile_state[tile] = 1u;
     } else if (tid == 0) {
         tile_state[tile] = 2u;
         atomicAnd(&live_bits[tty * ((vp.tiles_x + 31u) / 32u) + (ttx >> 5)], ~(1u << (ttx & 31u)));
         atomicSub(&ctl->live_tiles, 1u);
     }
-#ifdef GSX_DEBUG_COUNT
-#endif
     // the framebuffer always holds the composite of everything drawn so far over the clear colour
-    if (inside) {
-        cr += T * 0.05f; cg += T * 0.05f; cb += T * 0.05f;
-        const uint32_t r8 = static_cast<uint32_t>(fminf(fmaxf(cr, 0.0f), 1.0f) * 255.0f + 0.5f);
-        const uint32_t g8 = static_cast<uint32_t>(fminf(fmaxf(cg, 0.0f), 1.0f) * 255.0f + 0.5f);
-        const uint32_t b8 = static_cast<uint32_t>(fminf(fmaxf(cb, 0.0f), 1.0f) * 255.0f + 0.5f);
-        reinterpret_cast<uint32_t*>(fb)[static_cast<uint64_t>(py) * static_cast<uint32_t>(vp.width) + px] =
-            r8 | (g8 << 8) | (b8 << 16) | 0xFF000000u;
-    }
+    uint32_t* row = reinterpret_cast<uint32_t*>(fb) + static_cast<uint64_t>(py) * static_cast<uint32_t>(vp.width);
+    if (in0) row[px] = gsx_pack_rgba8(cr.x + T.x * 0.05f, cg.x + T.x * 0.05f, cb.x + T.x * 0.05f);
+    if (in1) row[px + 1] = gsx_pack_rgba8(cr.y + T.y * 0.05f, cg.y + T.y * 0.05f, cb.y + T.y * 0.05f);
 }
 
 // ---------------------------------------------------------------------------
@@ -696,13 +716,13 @@ static int launch_iteration(gsx_ctx* c, uint32_t iter, uint32_t window, bool fir
     if (c->profiling && iter < GSX_MAX_SCHED && !f.continuing) GSX_HIP(c, hipEventRecord(c->ev[EV_IT0 + 2 * iter], c->stream));
     const uint32_t fi = first ? 1u : 0u;
     if (f.mode == 0)
-        hipLaunchKernelGGL(k_raster<0>, dim3(f.n_tiles), dim3(256), 0, c->stream, c->tile_start, c->pair_val[cur], c->proj, c->color4, sorted, vp,
+        hipLaunchKernelGGL(k_raster<0>, dim3(f.n_tiles), dim3(GSX_RASTER_NT), 0, c->stream, c->tile_start, c->pair_val[cur], c->proj, c->color4, sorted, vp,
                            fi, c->tile_state, c->live_bits, c->accum, c->ctl, c->fb);
     else if (f.mode == 1)
-        hipLaunchKernelGGL(k_raster<1>, dim3(f.n_tiles), dim3(256), 0, c->stream, c->tile_start, c->pair_val[cur], c->proj, c->color4, sorted, vp,
+        hipLaunchKernelGGL(k_raster<1>, dim3(f.n_tiles), dim3(GSX_RASTER_NT), 0, c->stream, c->tile_start, c->pair_val[cur], c->proj, c->color4, sorted, vp,
                            fi, c->tile_state, c->live_bits, c->accum, c->ctl, c->fb);
     else
-        hipLaunchKernelGGL(k_raster<2>, dim3(f.n_tiles), dim3(256), 0, c->stream, c->tile_start, c->pair_val[cur], c->proj, c->color4, sorted, vp,
+        hipLaunchKernelGGL(k_raster<2>, dim3(f.n_tiles), dim3(GSX_RASTER_NT), 0, c->stream, c->tile_start, c->pair_val[cur], c->proj, c->color4, sorted, vp,
                            fi, c->tile_state, c->live_bits, c->accum, c->ctl, c->fb);
     if (c->profiling && iter < GSX_MAX_SCHED && !f.continuing) GSX_HIP(c, hipEventRecord(c->ev[EV_IT0 + 2 * iter + 1], c->stream));
     return GSX_OK;
