@@ -154,9 +154,16 @@ int gsx_get_keys(gsx_ctx* ctx, const float cam_pos[3], float* dist_out_host, uin
  * (SplatMesh.h:58; shader_quads_ordered.wgsl:42-73,120-212; main.cpp:338-344;
  * clear colour renderer.cpp:162-164).  Renders rows [y0,y1) of a width x height
  * RGBA8 frame from the last gsx_sort result.  rgba8_out_host (nullable)
- * receives width*height*4 bytes (rows outside the band untouched). ---- */
+ * receives width*height*4 bytes (rows outside the band untouched).
+ * Frame bands up to 4096 x 4096 pixels; larger -> GSX_E_UNSUPPORTED.
+ * With rgba8_out_host == NULL the call only QUEUES the frame (near -> far
+ * iterations).  The frame is complete, and the device
+ * framebuffer valid, after the next gsx_sync / gsx_get_timings / download;
+ * that call also runs the on-demand iterations a heavy frame may still need. ---- */
 int gsx_render(gsx_ctx* ctx, const gsx_uniforms* u, uint32_t width, uint32_t height,
                uint32_t y0, uint32_t y1, void* rgba8_out_host);
+/* Device pointer of the RGBA8 frame (valid until the next gsx_render with another size or gsx_destroy;
+ * contents complete after gsx_sync, see gsx_render). */
 int gsx_get_framebuffer_dev(gsx_ctx* ctx, const void** rgba8_dev, uint32_t* width, uint32_t* height);
 
 /* ---- host-only helpers (no GPU touched): the load-time half of ResourceManager and
