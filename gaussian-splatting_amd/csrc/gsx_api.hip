@@ -45,9 +45,7 @@ int check_flags(gsx_ctx* c) {
 
 int alloc_scene(gsx_ctx* c, uint64_t n) {
     int rc;
-    if ((rc = dev_alloc(c, &c->pos4, n)) || (rc = dev_alloc(c, &c->covA, n)) || (rc = dev_alloc(c, &c->covB, n)) ||
-        (rc = dev_alloc(c, &c->color4, n)))
-        return rc;
+    if ((rc = dev_alloc(c, &c->pos4, n)) || (rc = dev_alloc(c, &c->geo, n))) return rc;
     if ((rc = dev_alloc(c, &c->sel_idx, n))) return rc;
     c->sel_cap = n;
     for (int b = 0; b < 2; ++b)
@@ -55,8 +53,6 @@ int alloc_scene(gsx_ctx* c, uint64_t n) {
     c->sort_cap = n;
     c->sort_ws_words = gsx_sort_workspace_words(n);
     if ((rc = dev_alloc(c, &c->sort_ws, c->sort_ws_words))) return rc;
-    if ((rc = dev_alloc(c, &c->proj, n)) || (rc = dev_alloc(c, &c->tbox, n))) return rc;
-    c->proj_cap = n;
     // LOD / list-selection scratch (flags padded for 16-byte vector loads)
     const uint64_t fl = (n + 15) / 16 * 16 + 16;
     if ((rc = dev_alloc(c, &c->lod_stop, fl)) || (rc = dev_alloc(c, &c->lod_emit, fl))) return rc;
@@ -118,15 +114,15 @@ int gsx_destroy(gsx_ctx* c) {
     (void)hipSetDevice(c->device);
     c->frame_pending = false;
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    dev_free(&c->pos4); dev_free(&c->covA); dev_free(&c->covB); dev_free(&c->color4);
+    dev_free(&c->pos4); dev_free(&c->geo);
     dev_free(&c->sel_idx); dev_free(&c->m_dev);
     dev_free(&c->lod_a); dev_free(&c->lod_b); dev_free(&c->lod_parent); dev_free(&c->lod_leaf);
     dev_free(&c->lod_stop); dev_free(&c->lod_emit); dev_free(&c->lod_block_sums);
     for (int b = 0; b < 2; ++b) { dev_free(&c->keys[b]); dev_free(&c->vals[b]); dev_free(&c->pair_key[b]); dev_free(&c->pair_val[b]); }
     dev_free(&c->sort_ws); dev_free(&c->aabb_dev); dev_free(&c->flags); dev_free(&c->pair_ws);
-    dev_free(&c->proj); dev_free(&c->splat_ntiles); dev_free(&c->scan_block_sums);
+    dev_free(&c->splat_ntiles); dev_free(&c->scan_block_sums);
     dev_free(&c->tile_start); dev_free(&c->pair_total_dev); dev_free(&c->fb);
-    dev_free(&c->tbox); dev_free(&c->sub_off); dev_free(&c->rank_box); dev_free(&c->rank_pay); dev_free(&c->ctl); dev_free(&c->live_bits); dev_free(&c->tile_state); dev_free(&c->accum);
+    dev_free(&c->sub_off); dev_free(&c->rank_box); dev_free(&c->rank_rec); dev_free(&c->ctl); dev_free(&c->live_bits); dev_free(&c->tile_state); dev_free(&c->accum);
     if (c->ctl_host) (void)hipHostFree(c->ctl_host);
     if (c->frame_ev) (void)hipEventDestroy(c->frame_ev);
     if (c->host_word) (void)hipHostFree(c->host_word);
@@ -460,10 +456,8 @@ int gsx_debug_read(gsx_ctx* c, int what, void* out, uint64_t bytes) {
         case 6: src = c->sub_off; break;
         case 7: src = c->scan_block_sums; break;
         case 8: src = c->ctl; break;
-        case 9: src = c->tbox; break;
         case 10: src = c->tile_state; break;
         case 11: src = c->live_bits; break;
-        case 12: src = c->proj; break;
         case 13: src = c->accum; break;
         default: return GSX_E_INVALID;
     }

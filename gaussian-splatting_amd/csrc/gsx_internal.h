@@ -69,14 +69,20 @@ struct GsxDevFlags {
     uint32_t pad[3];
 };
 
-// Projected splat record (32 B), written by k_project in ORIGINAL splat order (the colour is not
-// copied: the rasterizer reads it from color4 directly).
-// Screen position of quad corner q in [-1,1]^2 is c + q.x*A + q.y*B (pixels);
+// Screen-space record of a projected splat: quad corner q in [-1,1]^2 sits at c + q.x*A + q.y*B (pixels);
 // m = cutOff * inverse([A B]) maps a pixel offset to the fragment's uv.
 struct GsxProj {
     float cx, cy;             // centre in pixels
-    float ex, ey;             // half extents of the quad's pixel bbox (|A|+|B| per axis); ex < 0 = culled
+    float ex, ey;             // half extents of the quad's pixel bbox (|A|+|B| per axis)
     float m00, m01, m10, m11; // u = m00*dx + m01*dy, v = m10*dx + m11*dy
+};
+
+// One 64-byte line per splat for everything the projection and the rasterizer read (gathered by sorted rank).
+struct GsxGeo {
+    float4 pos;     // transform[3]
+    float4 covA;    // s00 s01 s02 s11
+    float4 covB;    // s12 s22 0 0
+    float4 color;   // linear rgb + alpha
 };
 
 struct gsx_ctx {
@@ -91,9 +97,7 @@ struct gsx_ctx {
     // scene (SoA in HBM)
     uint64_t n = 0;
     float4* pos4 = nullptr;    // transform[3] (x,y,z,w)
-    float4* covA = nullptr;    // s00 s01 s02 s11
-    float4* covB = nullptr;    // s12 s22 0 0
-    float4* color4 = nullptr;
+    GsxGeo* geo = nullptr;     // AoS twin for the per-rank gathers of the frame loop (pos4 stays SoA for the key pass)
 
     // selection
     bool sel_iota = true;
@@ -134,8 +138,6 @@ struct gsx_ctx {
     GsxDevFlags* flags_host = nullptr; // pinned
 
     // raster
-    GsxProj* proj = nullptr;
-    uint64_t proj_cap = 0;
     uint32_t* splat_ntiles = nullptr;  // per sorted rank: number of tiles touched, then its exclusive scan
     uint32_t* scan_block_sums = nullptr;
     uint64_t rank_cap = 0;
@@ -154,10 +156,9 @@ struct gsx_ctx {
     uint64_t pair_grown = 0;           // budget a frame had to grow to (kept for later frames)
     uint32_t* sub_off = nullptr;       // per count block: 17 in-block pair offsets (64-rank boundaries)
     uint64_t sub_off_cap = 0;
-    uint32_t* rank_box = nullptr;      // per rank of the iteration's window: packed tile box / splat id, left by
-    uint32_t* rank_pay = nullptr;      // k_chunk_count for k_chunk_emit
-    uint64_t rank_box_cap = 0, rank_pay_cap = 0;
-    uint32_t* tbox = nullptr;          // per splat: packed tile box (capacity proj_cap)
+    uint32_t* rank_box = nullptr;      // per rank of the iteration's window: packed tile box (k_chunk_count -> k_chunk_emit)
+    float4* rank_rec = nullptr;        // per rank of the window: 48-B record (centre/extents, uv matrix, colour) for k_raster
+    uint64_t rank_box_cap = 0, rank_rec_cap = 0;
     GsxFrameCtl* ctl = nullptr;
     GsxFrameCtl* ctl_host = nullptr;   // pinned copy read after the frame
     uint32_t* live_bits = nullptr;     // GSX_MAX_TILES_Y x GSX_LIVE_ROW_WORDS: tiles still unsaturated

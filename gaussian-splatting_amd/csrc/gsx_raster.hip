@@ -55,15 +55,12 @@ __device__ __forceinline__ bool gsx_tile_bbox(float4 c, const GsxViewParams& vp,
 }
 
 // ---------------------------------------------------------------------------
-// K3: per-splat projection.
+// K3: per-splat projection = vs_main (wgsl:42-73) evaluated once per splat.  Device function: it runs inside
+// k_chunk_count on the ranks an iteration actually reaches (splats hidden behind retired tiles are never
+// projected).  Returns false for a culled splat; a = (cx, cy, ex, ey), mm = (m00, m01, m10, m11).
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_project(const float4* __restrict__ pos4, const float4* __restrict__ covA,
-                                                 const float4* __restrict__ covB,
-                                                 uint32_t n, GsxViewParams vp, GsxProj* __restrict__ out,
-                                                 uint32_t* __restrict__ tbox) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const float4 p = pos4[i], ca = covA[i], cb = covB[i];
+__device__ __forceinline__ bool gsx_project(const float4 p, const float4 ca, const float4 cb, const GsxViewParams& vp,
+                                            float4& a, float4& mm) {
     const float* W = vp.wt;  // column-major 4x4; W[c*4+r]
     // s_center = wt * sm[3]  (wgsl:53)
     float ctr[4];
@@ -131,15 +128,9 @@ __global__ __launch_bounds__(256) void k_project(const float4* __restrict__ pos4
         ok = (x1 >= x0) && (yy1 >= yy0) && (x1 >= 0.0f) && (x0 <= vp.width - 1.0f) && (yy1 >= static_cast<float>(vp.y0)) &&
              (yy0 <= static_cast<float>(vp.y1) - 1.0f);
     }
-    if (!ok) o.ex = -1.0f;
-    // 32-B record as two 16-B stores
-    float4* dst = reinterpret_cast<float4*>(out + i);
-    dst[0] = make_float4(o.cx, o.cy, o.ex, o.ey);
-    dst[1] = make_float4(o.m00, o.m01, o.m10, o.m11);
-    // 4-byte tile box for the binner (tx0 | ty0<<8 | tx1<<16 | ty1<<24; tx0 > tx1 = culled)
-    uint32_t tx0, tx1, ty0, ty1, tb = GSX_TBOX_NONE;
-    if (gsx_tile_bbox(make_float4(o.cx, o.cy, o.ex, o.ey), vp, tx0, tx1, ty0, ty1)) tb = tx0 | (ty0 << 8) | (tx1 << 16) | (ty1 << 24);
-    tbox[i] = tb;
+    a = make_float4(o.cx, o.cy, o.ex, o.ey);
+    mm = make_float4(o.m00, o.m01, o.m10, o.m11);
+    return ok;
 }
 
 // ---------------------------------------------------------------------------
@@ -199,20 +190,22 @@ __device__ __forceinline__ bool gsx_box_live(const uint32_t* s_live, uint32_t lw
     return false;
 }
 
-// Rank `local` (0 = nearest rank of the iteration) -> pair count; box = tx0 | ty0<<8 | (w-1)<<16 | (h-1)<<24 of its
-// tile box (GSX_RBOX_NONE when the splat is culled or every tile of the box is retired), pay = splat id.
+// Rank `local` (0 = nearest rank of the iteration) -> pair count.  The splat is projected here; box = tx0 | ty0<<8 |
+// (w-1)<<16 | (h-1)<<24 of its tile box (GSX_RBOX_NONE when it is culled or every tile of the box is retired).
 #define GSX_RBOX_NONE 0xFFFFFFFFu   // not a valid box: tx0 + (w-1) <= 255 always
 __device__ __forceinline__ uint32_t gsx_rank_pairs(uint32_t local, uint32_t win, uint32_t hi, const uint32_t* __restrict__ sorted,
-                                                   const uint32_t* __restrict__ tbox, const uint32_t* s_live, uint32_t lw,
-                                                   uint32_t& box, uint32_t& pay) {
+                                                   const GsxGeo* __restrict__ geo, const GsxViewParams& vp, const uint32_t* s_live,
+                                                   uint32_t lw, uint32_t& box, float4& a, float4& mm, float4& col) {
     if (local >= win) return 0u;
     const uint32_t r = hi - 1u - local;
     const uint32_t idx = sorted[r];
-    const uint32_t tb = tbox[idx];
-    const uint32_t tx0 = tb & 0xFFu, ty0 = (tb >> 8) & 0xFFu, tx1 = (tb >> 16) & 0xFFu, ty1 = tb >> 24;
-    if (tx0 > tx1 || !gsx_box_live(s_live, lw, tx0, tx1, ty0, ty1)) return 0u;
+    const float4* g = reinterpret_cast<const float4*>(geo + idx);     // one 64-B line per splat
+    const float4 p = g[0], ca = g[1], cb = g[2];
+    col = g[3];
+    if (!gsx_project(p, ca, cb, vp, a, mm)) return 0u;
+    uint32_t tx0, tx1, ty0, ty1;
+    if (!gsx_tile_bbox(a, vp, tx0, tx1, ty0, ty1) || !gsx_box_live(s_live, lw, tx0, tx1, ty0, ty1)) return 0u;
     box = tx0 | (ty0 << 8) | ((tx1 - tx0) << 16) | ((ty1 - ty0) << 24);
-    pay = idx;
     return (tx1 - tx0 + 1u) * (ty1 - ty0 + 1u);
 }
 
@@ -220,10 +213,11 @@ __device__ __forceinline__ uint32_t gsx_rank_pairs(uint32_t local, uint32_t win,
 // nearest first: pair count of the block -> block_sums[b], and the exclusive in-block pair offset at every
 // 64-rank boundary -> sub_off[b*17 + s] (s = 16 holds the block total).
 __global__ __launch_bounds__(GSX_BIN_NT) void k_chunk_count(const GsxFrameCtl* __restrict__ ctl, uint32_t iter, uint32_t window,
-                                                            const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ tbox,
-                                                            const uint32_t* __restrict__ live_bits, uint32_t tiles_x, uint32_t tiles_y,
+                                                            const uint32_t* __restrict__ sorted, const GsxGeo* __restrict__ geo,
+                                                            const uint32_t* __restrict__ live_bits, GsxViewParams vp,
                                                             uint32_t* __restrict__ block_sums, uint32_t* __restrict__ sub_off,
-                                                            uint32_t* __restrict__ rank_box, uint32_t* __restrict__ rank_pay) {
+                                                            uint32_t* __restrict__ rank_box, float4* __restrict__ rank_rec) {
+    const uint32_t tiles_x = vp.tiles_x, tiles_y = vp.tiles_y;
     __shared__ uint32_t s_tmp[GSX_BIN_NT / 64];
     __shared__ uint32_t s_live[GSX_MAX_TILES_Y * GSX_LIVE_ROW_WORDS];
     const uint32_t b = blockIdx.x;
@@ -239,16 +233,21 @@ __global__ __launch_bounds__(GSX_BIN_NT) void k_chunk_count(const GsxFrameCtl* _
     __syncthreads();
     uint32_t tot = 0;
     const uint32_t local0 = b * GSX_BIN_TILE + threadIdx.x * GSX_BIN_IPT;
-    uint32_t rb[GSX_BIN_IPT], rp[GSX_BIN_IPT];
-#pragma unroll
-    for (int j = 0; j < GSX_BIN_IPT; ++j) {
-        rb[j] = GSX_RBOX_NONE; rp[j] = 0u;
-        tot += gsx_rank_pairs(local0 + j, win, m - cur, sorted, tbox, s_live, lw, rb[j], rp[j]);
+    uint32_t rb[GSX_BIN_IPT];
+    for (int j = 0; j < GSX_BIN_IPT; ++j) {      // (not unrolled: the projection is long and register-hungry)
+        rb[j] = GSX_RBOX_NONE;
+        float4 a, mm, col;
+        const uint32_t cnt = gsx_rank_pairs(local0 + j, win, m - cur, sorted, geo, vp, s_live, lw, rb[j], a, mm, col);
+        if (cnt) {
+            // the 48-B screen-space record the rasterizer stages, in window-rank order
+            float4* rec = rank_rec + static_cast<uint64_t>(local0 + j) * 3;
+            rec[0] = a; rec[1] = mm; rec[2] = col;
+        }
+        tot += cnt;
     }
-    // what k_chunk_emit needs per rank, in rank order (so it never repeats the gathers above)
+    // what k_chunk_emit needs per rank, in rank order
     static_assert(GSX_BIN_IPT == 4, "one 16-byte store per thread");
     reinterpret_cast<uint4*>(rank_box)[local0 / 4] = make_uint4(rb[0], rb[1], rb[2], rb[3]);
-    reinterpret_cast<uint4*>(rank_pay)[local0 / 4] = make_uint4(rp[0], rp[1], rp[2], rp[3]);
     uint32_t block_total;
     const uint32_t excl = gsx_block_excl_scan<GSX_BIN_NT>(tot, s_tmp, &block_total);
     constexpr uint32_t TPS = GSX_BIN_NT / GSX_BIN_SUBS;          // threads per 64-rank sub-block
@@ -263,10 +262,9 @@ __global__ __launch_bounds__(GSX_BIN_NT) void k_chunk_count(const GsxFrameCtl* _
 // [block offset + sub offset, ...) in near -> far order.  The wave reads what k_chunk_count left per rank,
 // scans the 64 counts, and writes the pairs cooperatively (coalesced stores; every slot finds its rank by
 // binary search in the 65 offsets held in the wave's own LDS slice).  No workgroup barrier anywhere.
-template <bool RANK_PAYLOAD>
 __global__ __launch_bounds__(GSX_BIN_NT) void k_chunk_emit(const GsxFrameCtl* __restrict__ ctl, uint32_t iter, uint32_t tiles_x,
                                                            const uint32_t* __restrict__ block_sums, const uint32_t* __restrict__ sub_off,
-                                                           const uint32_t* __restrict__ rank_box, const uint32_t* __restrict__ rank_pay,
+                                                           const uint32_t* __restrict__ rank_box,
                                                            uint16_t* __restrict__ pair_key, uint32_t* __restrict__ pair_val) {
     constexpr uint32_t SUB = GSX_BIN_TILE / GSX_BIN_SUBS;        // 64 ranks
     constexpr uint32_t NW = GSX_BIN_NT / 64;
@@ -274,7 +272,6 @@ __global__ __launch_bounds__(GSX_BIN_NT) void k_chunk_emit(const GsxFrameCtl* __
     __shared__ uint32_t s_off[NW][SUB + 1], s_box[NW][SUB], s_pay[NW][SUB];
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t n_items = ctl->n_blocks * GSX_BIN_SUBS;       // sub-blocks of the blocks that fit the budget
-    const uint32_t hi = ctl->m - ctl->cursor[iter];
     uint32_t* off = s_off[wave];
     uint32_t* sbx = s_box[wave];
     uint32_t* spy = s_pay[wave];
@@ -286,7 +283,7 @@ __global__ __launch_bounds__(GSX_BIN_NT) void k_chunk_emit(const GsxFrameCtl* __
         if (sub_total == 0u) continue;                           // wave-uniform
         const uint32_t local = b * GSX_BIN_TILE + sb * SUB + lane;
         const uint32_t box = rank_box[local];
-        const uint32_t pay = RANK_PAYLOAD ? (hi - 1u - local) : rank_pay[local];
+        const uint32_t pay = local;                              // the pair names the splat by its rank inside the window
         const uint32_t cnt = box == GSX_RBOX_NONE ? 0u : (((box >> 16) & 0xFFu) + 1u) * ((box >> 24) + 1u);
         uint32_t incl = cnt;
 #pragma unroll
@@ -468,8 +465,7 @@ __device__ __forceinline__ uint32_t gsx_pack_rgba8(float r, float g, float b) {
 // shading loop is one packed-f32 instruction for both pixels (measured: the loop is VALU-bound).
 template <int MODE /*0 blend, 1 threshold (bayerSize 10), 2 bayer dither*/>
 __global__ __launch_bounds__(GSX_RASTER_NT) void k_raster(const uint32_t* __restrict__ tile_start, const uint32_t* __restrict__ pair_val,
-                                                          const GsxProj* __restrict__ proj, const float4* __restrict__ color4,
-                                                          const uint32_t* __restrict__ sorted, GsxViewParams vp, uint32_t first,
+                                                          const float4* __restrict__ rank_rec, uint32_t iter, GsxViewParams vp, uint32_t first,
                                                           uint32_t* __restrict__ tile_state, uint32_t* __restrict__ live_bits,
                                                           float4* __restrict__ accum, GsxFrameCtl* __restrict__ ctl,
                                                           uint8_t* __restrict__ fb) {
@@ -504,6 +500,7 @@ __global__ __launch_bounds__(GSX_RASTER_NT) void k_raster(const uint32_t* __rest
         cr = gsx_f2{a0.x, a1.x}; cg = gsx_f2{a0.y, a1.y}; cb = gsx_f2{a0.z, a1.z}; T = gsx_f2{a0.w, a1.w};
     }
     const float cut = vp.cut;
+    const uint32_t rank_hi = MODE == 2 ? ctl->m - ctl->cursor[iter] : 0u;
     // pixel-centre rectangle of half 0; half w is offset by 8 rows
     const float tx0f = static_cast<float>(tx * GSX_TILE_W) + 0.5f, ty0f = static_cast<float>(ty * GSX_TILE_H) + 0.5f;
     // near -> far: this iteration's list of the tile is already in that order
@@ -517,11 +514,11 @@ __global__ __launch_bounds__(GSX_RASTER_NT) void k_raster(const uint32_t* __rest
         const bool valid = tid < nb;
         float4 a = make_float4(0.0f, 0.0f, -1.0f, -1.0f), m = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         if (valid) {
-            uint32_t pv = pair_val[lo + tid];
-            if (MODE == 2) { s_rank[tid] = pv; pv = sorted[pv]; }
-            const float4* src = reinterpret_cast<const float4*>(proj + pv);
+            const uint32_t pv = pair_val[lo + tid];              // rank inside the iteration's window (0 = nearest)
+            if (MODE == 2) s_rank[tid] = rank_hi - 1u - pv;      // the draw's instance index = rank in the sorted order
+            const float4* src = rank_rec + static_cast<uint64_t>(pv) * 3;
             a = src[0]; m = src[1];
-            s_a[tid] = a; s_m[tid] = m; s_c[tid] = color4[pv];
+            s_a[tid] = a; s_m[tid] = m; s_c[tid] = src[2];
         }
         // (computed by every lane and masked with `valid` explicitly: lanes past the batch must
         // contribute 0 bits to the ballots below)
@@ -678,17 +675,13 @@ static int launch_iteration(gsx_ctx* c, uint32_t iter, uint32_t window, bool fir
     const uint32_t nb = gsx_div_up(window, GSX_BIN_TILE);
     const uint32_t budget = static_cast<uint32_t>(c->pair_cap);
     if (nb > 0) {
-        hipLaunchKernelGGL(k_chunk_count, dim3(nb), dim3(GSX_BIN_NT), 0, c->stream, c->ctl, iter, window, sorted, c->tbox,
-                           c->live_bits, vp.tiles_x, vp.tiles_y, c->scan_block_sums, c->sub_off, c->rank_box, c->rank_pay);
+        hipLaunchKernelGGL(k_chunk_count, dim3(nb), dim3(GSX_BIN_NT), 0, c->stream, c->ctl, iter, window, sorted, c->geo,
+                           c->live_bits, vp, c->scan_block_sums, c->sub_off, c->rank_box, c->rank_rec);
         hipLaunchKernelGGL(k_chunk_scan, dim3(1), dim3(1024), 0, c->stream, c->ctl, iter, window, nb, c->scan_block_sums, budget);
         const uint32_t waves = nb * GSX_BIN_SUBS;                       // one per 64-rank sub-block, capped
         const uint32_t emit_grid = gsx_div_up(waves, GSX_BIN_NT / 64) < 4096u ? gsx_div_up(waves, GSX_BIN_NT / 64) : 4096u;
-        if (f.mode == 2)
-            hipLaunchKernelGGL(k_chunk_emit<true>, dim3(emit_grid), dim3(GSX_BIN_NT), 0, c->stream, c->ctl, iter, vp.tiles_x,
-                               c->scan_block_sums, c->sub_off, c->rank_box, c->rank_pay, c->pair_key[0], c->pair_val[0]);
-        else
-            hipLaunchKernelGGL(k_chunk_emit<false>, dim3(emit_grid), dim3(GSX_BIN_NT), 0, c->stream, c->ctl, iter, vp.tiles_x,
-                               c->scan_block_sums, c->sub_off, c->rank_box, c->rank_pay, c->pair_key[0], c->pair_val[0]);
+        hipLaunchKernelGGL(k_chunk_emit, dim3(emit_grid), dim3(GSX_BIN_NT), 0, c->stream, c->ctl, iter, vp.tiles_x,
+                           c->scan_block_sums, c->sub_off, c->rank_box, c->pair_key[0], c->pair_val[0]);
     }
     // stable sort of the iteration's pairs by tile id; the pair count stays on the device
     const uint32_t* count_ptr = &c->ctl->pairs;
@@ -716,13 +709,13 @@ static int launch_iteration(gsx_ctx* c, uint32_t iter, uint32_t window, bool fir
     if (c->profiling && iter < GSX_MAX_SCHED && !f.continuing) GSX_HIP(c, hipEventRecord(c->ev[EV_IT0 + 2 * iter], c->stream));
     const uint32_t fi = first ? 1u : 0u;
     if (f.mode == 0)
-        hipLaunchKernelGGL(k_raster<0>, dim3(f.n_tiles), dim3(GSX_RASTER_NT), 0, c->stream, c->tile_start, c->pair_val[cur], c->proj, c->color4, sorted, vp,
+        hipLaunchKernelGGL(k_raster<0>, dim3(f.n_tiles), dim3(GSX_RASTER_NT), 0, c->stream, c->tile_start, c->pair_val[cur], c->rank_rec, iter, vp,
                            fi, c->tile_state, c->live_bits, c->accum, c->ctl, c->fb);
     else if (f.mode == 1)
-        hipLaunchKernelGGL(k_raster<1>, dim3(f.n_tiles), dim3(GSX_RASTER_NT), 0, c->stream, c->tile_start, c->pair_val[cur], c->proj, c->color4, sorted, vp,
+        hipLaunchKernelGGL(k_raster<1>, dim3(f.n_tiles), dim3(GSX_RASTER_NT), 0, c->stream, c->tile_start, c->pair_val[cur], c->rank_rec, iter, vp,
                            fi, c->tile_state, c->live_bits, c->accum, c->ctl, c->fb);
     else
-        hipLaunchKernelGGL(k_raster<2>, dim3(f.n_tiles), dim3(GSX_RASTER_NT), 0, c->stream, c->tile_start, c->pair_val[cur], c->proj, c->color4, sorted, vp,
+        hipLaunchKernelGGL(k_raster<2>, dim3(f.n_tiles), dim3(GSX_RASTER_NT), 0, c->stream, c->tile_start, c->pair_val[cur], c->rank_rec, iter, vp,
                            fi, c->tile_state, c->live_bits, c->accum, c->ctl, c->fb);
     if (c->profiling && iter < GSX_MAX_SCHED && !f.continuing) GSX_HIP(c, hipEventRecord(c->ev[EV_IT0 + 2 * iter + 1], c->stream));
     return GSX_OK;
@@ -758,7 +751,6 @@ int gsx_launch_render(gsx_ctx* c, const gsx_uniforms* u, uint32_t w, uint32_t h,
         c->err = "bayerSize must be 1, 10 or a power of two (the shader divides by zero otherwise)";
         return GSX_E_UNSUPPORTED;
     }
-    const uint32_t n = static_cast<uint32_t>(c->n);
     const uint32_t m_cap = c->m_cap;
 
     int rc;
@@ -775,7 +767,7 @@ int gsx_launch_render(gsx_ctx* c, const gsx_uniforms* u, uint32_t w, uint32_t h,
         if ((rc = ensure(c, &c->scan_block_sums, &c->rank_cap, nb_max)) != GSX_OK) return rc;
         if ((rc = ensure(c, &c->sub_off, &c->sub_off_cap, nb_max * (GSX_BIN_SUBS + 1))) != GSX_OK) return rc;
         if ((rc = ensure(c, &c->rank_box, &c->rank_box_cap, nb_max * GSX_BIN_TILE)) != GSX_OK) return rc;
-        if ((rc = ensure(c, &c->rank_pay, &c->rank_pay_cap, nb_max * GSX_BIN_TILE)) != GSX_OK) return rc;
+        if ((rc = ensure(c, &c->rank_rec, &c->rank_rec_cap, nb_max * GSX_BIN_TILE * 3)) != GSX_OK) return rc;
     }
     // pair budget: what one iteration may emit (the device cuts iterations to fit it)
     uint64_t budget = c->opt_pair_budget;
@@ -793,11 +785,8 @@ int gsx_launch_render(gsx_ctx* c, const gsx_uniforms* u, uint32_t w, uint32_t h,
     f.n_tiles = n_tiles;
     f.continuing = false;
 
-    // K3 (measured: running it on a second stream next to the depth sort gains nothing, the sort fills the chip)
+    // (K3, the projection, runs inside k_chunk_count on the ranks each iteration reaches)
     if (c->profiling) GSX_HIP(c, hipEventRecord(c->ev[EV_PROJ0], c->stream));
-    if (n > 0)
-        hipLaunchKernelGGL(k_project, dim3(gsx_div_up(n, 256)), dim3(256), 0, c->stream, c->pos4, c->covA, c->covB, n, vp,
-                           c->proj, c->tbox);
     hipLaunchKernelGGL(k_frame_init, dim3(gsx_div_up(n_tiles, 256)), dim3(256), 0, c->stream, c->ctl, c->m_dev, c->live_bits,
                        c->tile_state, vp.tiles_x, vp.tiles_y);
     if (c->profiling) GSX_HIP(c, hipEventRecord(c->ev[EV_PROJ1], c->stream));

@@ -10,20 +10,22 @@
 #include <cstring>
 
 // ---------------------------------------------------------------------------
-// Upload: 80-B AoS `Splat` (Splat.h:19-29) -> SoA float4 arrays.
+// Upload: 80-B AoS `Splat` (Splat.h:19-29) -> SoA positions (key pass) + 64-B AoS records (frame loop).
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_upload_soa(const float4* __restrict__ aos, uint64_t n,
-                                                    float4* __restrict__ pos4, float4* __restrict__ covA,
-                                                    float4* __restrict__ covB, float4* __restrict__ color4,
+                                                    float4* __restrict__ pos4, GsxGeo* __restrict__ geo,
                                                     GsxDevFlags* __restrict__ flags) {
     const uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float4 c0 = aos[i * 5 + 0], c1 = aos[i * 5 + 1], c2 = aos[i * 5 + 2];
-    pos4[i] = aos[i * 5 + 3];
-    color4[i] = aos[i * 5 + 4];
+    const float4 pos = aos[i * 5 + 3];
+    pos4[i] = pos;
     // column-major: c0 = (s00,s10,s20,_), c1 = (s01,s11,s21,_), c2 = (s02,s12,s22,_)
-    covA[i] = make_float4(c0.x, c1.x, c2.x, c1.y);
-    covB[i] = make_float4(c2.y, c2.z, 0.0f, 0.0f);
+    float4* g = reinterpret_cast<float4*>(geo + i);
+    g[0] = pos;
+    g[1] = make_float4(c0.x, c1.x, c2.x, c1.y);
+    g[2] = make_float4(c2.y, c2.z, 0.0f, 0.0f);
+    g[3] = aos[i * 5 + 4];
     const bool sym = (__float_as_uint(c0.y) == __float_as_uint(c1.x)) && (__float_as_uint(c0.z) == __float_as_uint(c2.x)) &&
                      (__float_as_uint(c1.z) == __float_as_uint(c2.y));
     // +0/-0 and NaN payload differences do not matter to the projection; compare by value too
@@ -35,7 +37,7 @@ __global__ __launch_bounds__(256) void k_upload_soa(const float4* __restrict__ a
 int gsx_launch_upload(gsx_ctx* c, const void* aos80_dev, uint64_t n) {
     if (n == 0) return GSX_OK;
     hipLaunchKernelGGL(k_upload_soa, dim3(gsx_div_up(n, 256)), dim3(256), 0, c->stream,
-                       static_cast<const float4*>(aos80_dev), n, c->pos4, c->covA, c->covB, c->color4, c->flags);
+                       static_cast<const float4*>(aos80_dev), n, c->pos4, c->geo, c->flags);
     GSX_HIP(c, hipGetLastError());
     return GSX_OK;
 }
