@@ -190,18 +190,11 @@ __device__ __forceinline__ bool gsx_box_live(const uint32_t* s_live, uint32_t lw
     return false;
 }
 
-// Rank `local` (0 = nearest rank of the iteration) -> pair count.  The splat is projected here; box = tx0 | ty0<<8 |
-// (w-1)<<16 | (h-1)<<24 of its tile box (GSX_RBOX_NONE when it is culled or every tile of the box is retired).
+// Projected rank -> pair count; box = tx0 | ty0<<8 | (w-1)<<16 | (h-1)<<24 of its tile box (GSX_RBOX_NONE when the
+// splat is culled or every tile of the box is retired).
 #define GSX_RBOX_NONE 0xFFFFFFFFu   // not a valid box: tx0 + (w-1) <= 255 always
-__device__ __forceinline__ uint32_t gsx_rank_pairs(uint32_t local, uint32_t win, uint32_t hi, const uint32_t* __restrict__ sorted,
-                                                   const GsxGeo* __restrict__ geo, const GsxViewParams& vp, const uint32_t* s_live,
-                                                   uint32_t lw, uint32_t& box, float4& a, float4& mm, float4& col) {
-    if (local >= win) return 0u;
-    const uint32_t r = hi - 1u - local;
-    const uint32_t idx = sorted[r];
-    const float4* g = reinterpret_cast<const float4*>(geo + idx);     // one 64-B line per splat
-    const float4 p = g[0], ca = g[1], cb = g[2];
-    col = g[3];
+__device__ __forceinline__ uint32_t gsx_rank_pairs(const float4 p, const float4 ca, const float4 cb, const GsxViewParams& vp,
+                                                   const uint32_t* s_live, uint32_t lw, uint32_t& box, float4& a, float4& mm) {
     if (!gsx_project(p, ca, cb, vp, a, mm)) return 0u;
     uint32_t tx0, tx1, ty0, ty1;
     if (!gsx_tile_bbox(a, vp, tx0, tx1, ty0, ty1) || !gsx_box_live(s_live, lw, tx0, tx1, ty0, ty1)) return 0u;
@@ -233,11 +226,22 @@ __global__ __launch_bounds__(GSX_BIN_NT) void k_chunk_count(const GsxFrameCtl* _
     __syncthreads();
     uint32_t tot = 0;
     const uint32_t local0 = b * GSX_BIN_TILE + threadIdx.x * GSX_BIN_IPT;
+    // all gathers of the thread's four ranks are issued before any projection starts (one 64-B line per splat)
     uint32_t rb[GSX_BIN_IPT];
-    for (int j = 0; j < GSX_BIN_IPT; ++j) {      // (not unrolled: the projection is long and register-hungry)
+    float4 gp[GSX_BIN_IPT], ga[GSX_BIN_IPT], gb[GSX_BIN_IPT], gc[GSX_BIN_IPT];
+    const uint32_t hi = m - cur;
+#pragma unroll
+    for (int j = 0; j < GSX_BIN_IPT; ++j) {
+        const uint32_t local = local0 + j;
+        const uint32_t idx = sorted[hi - 1u - (local < win ? local : win - 1u)];
+        const float4* g = reinterpret_cast<const float4*>(geo + idx);
+        gp[j] = g[0]; ga[j] = g[1]; gb[j] = g[2]; gc[j] = g[3];
+    }
+    for (int j = 0; j < GSX_BIN_IPT; ++j) {      // (not unrolled: the projection is long)
         rb[j] = GSX_RBOX_NONE;
-        float4 a, mm, col;
-        const uint32_t cnt = gsx_rank_pairs(local0 + j, win, m - cur, sorted, geo, vp, s_live, lw, rb[j], a, mm, col);
+        float4 a, mm;
+        const float4 col = gc[j];
+        const uint32_t cnt = (local0 + j < win) ? gsx_rank_pairs(gp[j], ga[j], gb[j], vp, s_live, lw, rb[j], a, mm) : 0u;
         if (cnt) {
             // the 48-B screen-space record the rasterizer stages, in window-rank order
             float4* rec = rank_rec + static_cast<uint64_t>(local0 + j) * 3;
