@@ -215,3 +215,70 @@ def test_set_option_rejects_unknown(gsx_fresh, pkg):
         gsx.set_option("no_such_knob", 1)
     with pytest.raises(pkg.GsxError):
         gsx.set_option("chunk_growth", 1)
+
+
+def test_large_render_properties(gsx_fresh, pkg, oracle, synth):
+    """cfg-2 size (6M splats, 1920x1080): the image oracle would take minutes, so check size-independent
+    properties of the frame loop instead."""
+    gsx = gsx_fresh
+    n, w, h = 6_000_000, 1920, 1080
+    splats = oracle.raw_to_splat(synth.clustered_cloud(n, seed=6))
+    view, proj, cam = camera(oracle, w, h)
+    u = pkg.make_uniforms(proj, view)
+    gsx.upload(splats)
+    perm = gsx.sort(cam)
+    gsx.set_option("no_history", 1)
+    img = gsx.render(u, w, h)
+    t = gsx.timings()
+    assert np.all(img[..., 3] == 255) and img[..., :3].std() > 10
+    assert 2 <= t["render_iters"] <= 8 and t["tile_pairs"] < 40_000_000      # occlusion culling at work (one shot: 76 M pairs)
+    # (1) determinism
+    assert np.array_equal(gsx.render(u, w, h), img)
+    # (2) tile bands (the multi-GPU sharding unit) compose byte-exactly when they share the rank schedule
+    out = np.zeros_like(img)
+    for y0, y1 in ((0, 272), (272, 544), (544, 816), (816, 1080)):
+        gsx.render(u, w, h, y0, y1, out=out)
+    assert np.array_equal(out, img)
+    # (3) one-shot binning (no occlusion culling inside the iteration; cut only by the pair budget) gives the same
+    #     picture up to the saturation cut-off
+    gsx.set_option("chunk_first", 1 << 30)
+    one = gsx.render(u, w, h)
+    t1 = gsx.timings()
+    assert t1["tile_pairs"] > 2 * t["tile_pairs"]
+    assert np.abs(one.astype(np.int32) - img.astype(np.int32)).max() <= 1
+    gsx.set_option("chunk_first", 0)
+    # (4) everything behind the nearest third of the splats is hidden in this scene: drawing only those gives the same picture
+    gsx.select_list(np.sort(perm[-2_000_000:]))
+    gsx.sort(cam)
+    near = gsx.render(u, w, h)
+    assert np.abs(near.astype(np.int32) - img.astype(np.int32)).max() <= 1
+    gsx.select_all()
+    # (5) with the history-based schedule (default) frames still agree to one level
+    gsx.set_option("no_history", 0)
+    gsx.sort(cam)
+    for _ in range(3):
+        again = gsx.render(u, w, h)
+        assert np.abs(again.astype(np.int32) - img.astype(np.int32)).max() <= 1
+
+
+def test_large_overlap_4k_bands(gsx_fresh, pkg, oracle, synth):
+    """cfg 5: 6M-splat overlap-stress scene at 3840x2160 in 8 horizontal bands (one per GPU of a node)."""
+    gsx = gsx_fresh
+    n, w, h = 6_000_000, 3840, 2160
+    splats = oracle.raw_to_splat(synth.overlap_stress_cloud(n))
+    view, proj, cam = camera(oracle, w, h)
+    u = pkg.make_uniforms(proj, view)
+    gsx.upload(splats)
+    gsx.sort(cam)
+    gsx.set_option("no_history", 1)
+    img = gsx.render(u, w, h)
+    assert img[..., :3].std() > 10
+    aligned = np.zeros_like(img)
+    for b in range(8):                                   # tile-aligned bands: 7 x 272 rows + 256
+        gsx.render(u, w, h, b * 272, min((b + 1) * 272, h), out=aligned)
+    # (the pair budget cuts this scene's iterations, and it cuts a band elsewhere than the whole frame: one level)
+    assert np.abs(aligned.astype(np.int32) - img.astype(np.int32)).max() <= 1
+    ragged = np.zeros_like(img)
+    for b in range(8):                                   # 270-row bands as in SURVEY 8(d): boundaries inside tiles
+        gsx.render(u, w, h, b * 270, (b + 1) * 270, out=ragged)
+    assert np.abs(ragged.astype(np.int32) - img.astype(np.int32)).max() <= 1
