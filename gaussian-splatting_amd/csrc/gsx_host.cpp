@@ -11,6 +11,7 @@
 #include "../host/gsx_lod_host.hpp"
 #include "../host/gsx_scene.hpp"
 #include "../host/gsx_splat.hpp"
+#include "../host/gsx_ply.hpp"
 
 using namespace gsx;
 
@@ -52,6 +53,46 @@ int gsx_host_load_splat_file(const char* path, int center, void** aos80_out, uin
 }
 
 void gsx_host_free(void* p) { std::free(p); }
+
+int gsx_host_load_ply_raw(const char* path, void** raw32_out, uint64_t* n_out) {
+    if (!path || !raw32_out || !n_out) return GSX_E_INVALID;
+    *raw32_out = nullptr;
+    *n_out = 0;
+    std::vector<SplatRaw> raw;
+    PlyStatus st;
+    try {
+        st = load_ply_raw(path, raw);
+    } catch (const std::bad_alloc&) {
+        return GSX_E_NOMEM;
+    }
+    if (st == PlyStatus::CannotOpen) return GSX_OK;              // missing file == empty scene, like loadSplatsRaw
+    if (st == PlyStatus::Unsupported) return GSX_E_UNSUPPORTED;
+    if (st != PlyStatus::Ok) return GSX_E_INVALID;
+    if (raw.empty()) return GSX_OK;
+    void* out = std::malloc(raw.size() * sizeof(SplatRaw));
+    if (!out) return GSX_E_NOMEM;
+    std::memcpy(out, raw.data(), raw.size() * sizeof(SplatRaw));
+    *raw32_out = out;
+    *n_out = raw.size();
+    return GSX_OK;
+}
+
+int gsx_host_load_ply_file(const char* path, int center, void** aos80_out, uint64_t* n_out) {
+    if (!aos80_out || !n_out) return GSX_E_INVALID;
+    *aos80_out = nullptr;
+    void* raw = nullptr;
+    uint64_t n = 0;
+    int rc = gsx_host_load_ply_raw(path, &raw, &n);
+    *n_out = n;
+    if (rc != GSX_OK || n == 0) return rc;
+    void* out = std::malloc(n * sizeof(Splat));
+    if (!out) { std::free(raw); *n_out = 0; return GSX_E_NOMEM; }
+    rc = gsx_host_convert_raw(raw, n, center, out);
+    std::free(raw);
+    if (rc != GSX_OK) { std::free(out); *n_out = 0; return rc; }
+    *aos80_out = out;
+    return GSX_OK;
+}
 
 int gsx_host_camera(const float world16[16], float fov_deg, float aspect, float znear, float zfar, float view16[16],
                     float proj16[16], float viewproj16[16]) {

@@ -28,6 +28,7 @@
 
 #include "../../include/gsx.h"
 #include "gsx_lod_host.hpp"
+#include "gsx_ply.hpp"
 #include "gsx_scene.hpp"
 #include "gsx_splat.hpp"
 
@@ -210,7 +211,7 @@ public:
     }
 
     virtual void loadData(const std::string& path, bool center) {  // SplatMesh.h:61-70
-        SplatSplitVector s = loadSplatsRaw(path, center);
+        SplatSplitVector s = loadSplatsAny(path, center);   // .splat as the reference; .ply too (gsx_ply.hpp)
         splatData.resize(s.size());
         for (size_t i = 0; i < s.size(); ++i) splatData[i] = split_to_splat(s[i]);
         indices.resize(splatData.size());
@@ -332,7 +333,7 @@ public:
         sortAndDraw(renderPass, xyz(camera->worldMatrix[3]), static_cast<uint32_t>(splatData.size()));
     }
     void loadData(const std::string& path, bool center) override {  // SplatMeshOctree.hpp:57-79
-        SplatSplitVector s = loadSplatsRaw(path, center);
+        SplatSplitVector s = loadSplatsAny(path, center);   // .splat as the reference; .ply too (gsx_ply.hpp)
         octree.build(s);
         octree.generate();
         splatData = octree.splats;
@@ -364,7 +365,7 @@ public:
         sortAndDraw(renderPass, xyz(camera->worldMatrix[3]), static_cast<uint32_t>(splatData.size()));
     }
     void loadData(const std::string& path, bool center) override {  // SplatMeshHC.hpp:58-91
-        SplatSplitVector s = loadSplatsRaw(path, center);
+        SplatSplitVector s = loadSplatsAny(path, center);   // .splat as the reference; .ply too (gsx_ply.hpp)
         SplatVector splats(s.size());
         for (size_t i = 0; i < s.size(); ++i) splats[i] = split_to_splat(s[i]);
         const uint32_t maxSplats = 500;
@@ -411,7 +412,7 @@ public:
         sortAndDraw(renderPass, cameraPos, static_cast<uint32_t>(splatData.size()));
     }
     void loadData(const std::string& path, bool center) override {  // SplatMeshGridHC.cpp:26-52
-        SplatSplitVector s = loadSplatsRaw(path, center);
+        SplatSplitVector s = loadSplatsAny(path, center);   // .splat as the reference; .ply too (gsx_ply.hpp)
         SplatVector splats(s.size());
         for (size_t i = 0; i < s.size(); ++i) splats[i] = split_to_splat(s[i]);
         const uint32_t maxSplats = 1000000;

@@ -176,6 +176,15 @@ int gsx_host_convert_raw(const void* raw32_host, uint64_t n, int center, void* a
  * empty vector.  *aos80_out is malloc'ed; release with gsx_host_free. */
 int gsx_host_load_splat_file(const char* path, int center, void** aos80_out, uint64_t* n_out);
 void gsx_host_free(void* p);
+/* 3D-Gaussian-splatting PLY input (INRIA training output).  No counterpart in the reference
+ * (its configs name .ply files but ResourceManager.cpp:36-65 reads only 32-byte .splat records): the PLY is
+ * converted to exactly those records (host/gsx_ply.hpp states the conversion), after which the reference's own
+ * raw_to_split / split_to_splat path applies.  *_raw yields n 32-byte SplatRaw records, *_file the 80-byte Splat
+ * records ready for gsx_upload_splats.  Missing file -> n = 0 and GSX_OK (as loadSplatsRaw); ASCII / big-endian /
+ * list properties -> GSX_E_UNSUPPORTED; broken header, missing property or truncated data -> GSX_E_INVALID.
+ * Outputs are malloc'ed; release with gsx_host_free. */
+int gsx_host_load_ply_raw(const char* path, void** raw32_out, uint64_t* n_out);
+int gsx_host_load_ply_file(const char* path, int center, void** aos80_out, uint64_t* n_out);
 /* Camera::getViewMatrix / getProjectionMatrix (Camera.h:27-34) and proj*view (BB.hpp:60-61).
  * Any output pointer may be NULL. */
 int gsx_host_camera(const float world16[16], float fov_deg, float aspect, float znear, float zfar,

@@ -3,6 +3,7 @@ reference-generated fixtures, bit for bit.  No GPU is touched."""
 import importlib
 
 import numpy as np
+import pytest
 
 from conftest import bits, golden
 
@@ -98,3 +99,66 @@ def test_gridhc_build_matches_reference(pkg, oracle):
     for p in range(3):
         for ti, thr in enumerate(g["g_mthr"]):
             assert np.array_equal(t.cut_camera(g["pose_world"][p], float(thr)), g[f"g_cut_metric_p{p}_t{ti}"])
+
+
+def _ply_fields(n, seed):
+    rng = np.random.default_rng(seed)
+    xyz = rng.uniform(-2, 2, (n, 3)).astype(np.float32)
+    f_dc = rng.normal(0, 1.2, (n, 3)).astype(np.float32)            # some colours clamp at 0 / 255
+    opacity = rng.normal(0, 3, n).astype(np.float32)
+    log_scale = rng.uniform(-6, -2, (n, 3)).astype(np.float32)
+    rot = rng.normal(0, 1, (n, 4)).astype(np.float32)
+    return xyz, f_dc, opacity, log_scale, rot
+
+
+def _expected_raw(xyz, f_dc, opacity, log_scale, rot):
+    """The conversion host/gsx_ply.hpp documents, in float64 numpy."""
+    n = len(xyz)
+    raw = np.zeros((n, 32), np.uint8)
+    raw[:, 0:12] = xyz.astype(np.float32).view(np.uint8).reshape(n, 12)
+    raw[:, 12:24] = np.exp(log_scale.astype(np.float64)).astype(np.float32).view(np.uint8).reshape(n, 12)
+    u8 = lambda v: np.clip(np.rint(np.clip(v, 0, 255)), 0, 255).astype(np.uint8)
+    raw[:, 24:27] = u8((0.5 + 0.28209479177387814 * f_dc.astype(np.float64)) * 255.0)
+    raw[:, 27] = u8(255.0 / (1.0 + np.exp(-opacity.astype(np.float64))))
+    q = rot.astype(np.float64)
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    raw[:, 28:32] = u8(q * 128.0 + 128.0)
+    return raw
+
+
+def test_ply_reader(pkg, oracle, tmp_path):
+    """3DGS PLY -> the reference's 32-byte records -> Splat (parity unpinned: the reference has no
+    PLY reader; everything after the records is its own raw_to_split path, pinned above)."""
+    scene = importlib.import_module("gaussian_splatting_amd.scene")
+    fields = _ply_fields(1000, 5)
+    want = _expected_raw(*fields)
+    p1 = tmp_path / "a.ply"
+    scene.save_ply_file(p1, *fields, extra_rest=45)                  # degree-3 SH payload is skipped
+    got = scene.load_ply_raw(pkg, p1)
+    assert got.shape == want.shape
+    assert np.array_equal(got[:, :24], want[:, :24])                 # positions, exp(scale): exact f32
+    assert np.abs(got[:, 24:].astype(int) - want[:, 24:].astype(int)).max() <= 1   # u8 fields (libm vs numpy exp at .5)
+    assert (got[:, 24:] != want[:, 24:]).mean() < 0.01
+    # property order does not matter
+    order = ["rot_3", "opacity", "z", "f_dc_2", "scale_1", "x", "rot_0", "f_dc_0", "y", "scale_0", "rot_1", "f_dc_1", "scale_2", "rot_2"]
+    p2 = tmp_path / "b.ply"
+    scene.save_ply_file(p2, *fields, order=order)
+    assert np.array_equal(scene.load_ply_raw(pkg, p2), got)
+    # the Splat records are what the reference's path makes of those 32-byte records
+    splats = scene.load_ply_file(pkg, p1, center=True)
+    assert np.array_equal(bits(splats), bits(oracle.raw_to_splat(got, center=True)))
+    # error behaviour
+    assert scene.load_ply_raw(pkg, tmp_path / "missing.ply").shape == (0, 32)       # like loadSplatsRaw: empty scene
+    (tmp_path / "ascii.ply").write_text("ply\nformat ascii 1.0\nelement vertex 1\nproperty float x\nend_header\n0\n")
+    with pytest.raises(pkg.GsxError) as e:
+        scene.load_ply_raw(pkg, tmp_path / "ascii.ply")
+    assert e.value.code == pkg.GSX_E_UNSUPPORTED
+    data = open(p1, "rb").read()
+    (tmp_path / "short.ply").write_bytes(data[:-100])
+    with pytest.raises(pkg.GsxError) as e:
+        scene.load_ply_raw(pkg, tmp_path / "short.ply")
+    assert e.value.code == pkg.GSX_E_INVALID
+    (tmp_path / "noprop.ply").write_bytes(data.replace(b"property float opacity\n", b"property float opacitx\n"))
+    with pytest.raises(pkg.GsxError) as e:
+        scene.load_ply_raw(pkg, tmp_path / "noprop.ply")
+    assert e.value.code == pkg.GSX_E_INVALID
