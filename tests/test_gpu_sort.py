@@ -211,3 +211,25 @@ def test_large_sort_properties(gsx, oracle, synth):
     gsx.select_list(sub)
     assert np.array_equal(gsx.sort(cam), oracle.sort_contract(splats, cam, sub))
     gsx.select_all()
+
+
+def test_octree_select_large_orbit(gsx, pkg, oracle, synth):
+    """cfg-3 shape at 1M splats (1.45M octree nodes): the device cut equals the CPU restatement of Octree::get_indices
+    along an orbit, and the LOD -> sort chain stays on the device."""
+    import importlib
+    lod = importlib.import_module("gaussian_splatting_amd.lod")
+    t = lod.build_octree(synth.clustered_cloud(1_000_000, seed=6))    # host builder, bit-exact with the reference (test_host.py)
+    t.upload(gsx)
+    for steps in (0, 40, 80):                                         # frames of a 120-frame orbit
+        world, _ = oracle.orbit_world(5.0, (0.0, 1.0, 0.0), 2.0 * np.pi / 120.0, steps)
+        view, proj, vp, cam = oracle.camera(world, 45.0, 16.0 / 9.0)
+        for thr in (0.002, 0.0002):                                   # min_screen_area 0.2 * 0.01 (SplatMeshOctree.hpp:44) and a finer cut
+            ref_cut = oracle.octree_cut(t.center3, t.half3, t.first_child, t.n_children, vp, np.float32(thr))
+            m = gsx.select_octree(vp, float(thr))
+            assert m == len(ref_cut) and 0 < m < t.n
+            assert np.array_equal(gsx.selection(), ref_cut)
+        perm = gsx.sort(cam)
+        k = oracle.distance_keys(t.splats, cam)[perm]
+        assert np.all(k[:-1] >= k[1:]) and np.array_equal(np.sort(perm), ref_cut)
+    gsx.select_all()
+    t.close()
