@@ -92,6 +92,8 @@ int gsx_create(int device, gsx_ctx** out) {
         if (hipEventCreate(&c->ev[i]) != hipSuccess) return fail(GSX_E_HIP);
     if (hipEventCreateWithFlags(&c->frame_ev, hipEventDisableTiming) != hipSuccess) return fail(GSX_E_HIP);
     if (hipMalloc(reinterpret_cast<void**>(&c->ctl), sizeof(GsxFrameCtl)) != hipSuccess) return fail(GSX_E_NOMEM);
+    if (hipMalloc(reinterpret_cast<void**>(&c->aux), 128) != hipSuccess) return fail(GSX_E_NOMEM);
+    if (hipHostMalloc(reinterpret_cast<void**>(&c->aux_host), 128, hipHostMallocDefault) != hipSuccess) return fail(GSX_E_NOMEM);
     if (hipMalloc(reinterpret_cast<void**>(&c->live_bits), GSX_MAX_TILES_Y * GSX_LIVE_ROW_WORDS * 4) != hipSuccess) return fail(GSX_E_NOMEM);
     if (hipHostMalloc(reinterpret_cast<void**>(&c->ctl_host), sizeof(GsxFrameCtl), hipHostMallocDefault) != hipSuccess)
         return fail(GSX_E_NOMEM);
@@ -124,6 +126,8 @@ int gsx_destroy(gsx_ctx* c) {
     dev_free(&c->tile_start); dev_free(&c->pair_total_dev); dev_free(&c->fb);
     dev_free(&c->sub_off); dev_free(&c->rank_box); dev_free(&c->rank_rec); dev_free(&c->ctl); dev_free(&c->live_bits); dev_free(&c->tile_state); dev_free(&c->accum);
     if (c->ctl_host) (void)hipHostFree(c->ctl_host);
+    if (c->aux_host) (void)hipHostFree(c->aux_host);
+    dev_free(&c->aux);
     if (c->frame_ev) (void)hipEventDestroy(c->frame_ev);
     if (c->host_word) (void)hipHostFree(c->host_word);
     if (c->flags_host) (void)hipHostFree(c->flags_host);

@@ -161,6 +161,11 @@ struct gsx_ctx {
     uint64_t rank_box_cap = 0, rank_rec_cap = 0;
     GsxFrameCtl* ctl = nullptr;
     GsxFrameCtl* ctl_host = nullptr;   // pinned copy read after the frame
+    // aux[0] = cursor of the running iteration (plain data), aux[16] = ranks from the near end consumed by the tiles
+    // retired so far (atomicMax).  Kept OFF the control block's cache line: that line is hammered by returnless
+    // atomics while tiles retire, and any load from it then queues behind them (measured: raster 3x slower).
+    uint32_t* aux = nullptr;
+    uint32_t* aux_host = nullptr;      // pinned, 32 words
     uint32_t* live_bits = nullptr;     // GSX_MAX_TILES_Y x GSX_LIVE_ROW_WORDS: tiles still unsaturated
     uint32_t* tile_state = nullptr;    // per tile: 0 untouched, 1 accumulators valid, 2 retired
     uint64_t tile_state_cap = 0;

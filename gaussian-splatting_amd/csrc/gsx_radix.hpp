@@ -63,18 +63,22 @@ __device__ __forceinline__ uint32_t gsx_block_excl_scan(uint32_t v, uint32_t* s_
     return wave_off + incl - v;
 }
 
-// Lanes of the wave holding the same digit as this lane (all 64 lanes must call).
+// Lanes of the wave holding the same digit as this lane (all 64 lanes must call).  Per digit bit: one ballot,
+// then every lane ORs in the lanes whose bit differs from its own (ballot ^ -mybit); kept in 32-bit halves so
+// that a bit costs ~6 VALU instructions (a 64-bit select-and-AND formulation compiled to 9).
 __device__ __forceinline__ uint64_t gsx_match_digit(uint32_t d, uint32_t bits) {
-    uint64_t peers = ~0ull;
+    uint32_t mis_lo = 0u, mis_hi = 0u;
 #pragma unroll
     for (int b = 0; b < GSX_RADIX_MAX_BITS; ++b) {
         if (static_cast<uint32_t>(b) < bits) {   // wave-uniform
-            const bool bit = (d >> b) & 1u;
-            const uint64_t bal = __builtin_amdgcn_ballot_w64(bit);
-            peers &= bit ? bal : ~bal;
+            const uint32_t bit = (d >> b) & 1u;
+            const uint64_t bal = __builtin_amdgcn_ballot_w64(bit != 0u);
+            const uint32_t mine = 0u - bit;                         // 0 or 0xFFFFFFFF
+            mis_lo |= static_cast<uint32_t>(bal) ^ mine;
+            mis_hi |= static_cast<uint32_t>(bal >> 32) ^ mine;
         }
     }
-    return peers;
+    return ~((static_cast<uint64_t>(mis_hi) << 32) | mis_lo);
 }
 
 // Logical range index of this workgroup.  Workgroups are dealt round-robin over the 8

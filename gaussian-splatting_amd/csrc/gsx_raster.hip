@@ -157,9 +157,10 @@ __device__ __forceinline__ bool gsx_project(const float4 p, const float4 ca, con
 
 __global__ __launch_bounds__(256) void k_frame_init(GsxFrameCtl* __restrict__ ctl, const uint32_t* __restrict__ m_ptr,
                                                     uint32_t* __restrict__ live_bits, uint32_t* __restrict__ tile_state,
-                                                    uint32_t tiles_x, uint32_t tiles_y) {
+                                                    uint32_t tiles_x, uint32_t tiles_y, uint32_t* __restrict__ aux) {
     const uint32_t lw = (tiles_x + 31u) / 32u, n_tiles = tiles_x * tiles_y;
     const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x, gsz = gridDim.x * blockDim.x;
+    if (gtid < 32) aux[gtid] = 0u;
     if (gtid < sizeof(GsxFrameCtl) / 4) {
         uint32_t v = 0;
         if (gtid == offsetof(GsxFrameCtl, m) / 4) v = *m_ptr;
@@ -345,7 +346,8 @@ __device__ __forceinline__ unsigned long long gsx_scan1024_u64(unsigned long lon
 // K4s.  One workgroup: exclusive scan of the iteration's block sums (in place), the number of leading
 // blocks whose pairs fit `budget`, and the cursor of the next iteration.
 __global__ __launch_bounds__(1024) void k_chunk_scan(GsxFrameCtl* __restrict__ ctl, uint32_t iter, uint32_t window,
-                                                     uint32_t nb, uint32_t* __restrict__ sums, uint32_t budget) {
+                                                     uint32_t nb, uint32_t* __restrict__ sums, uint32_t budget,
+                                                     uint32_t* __restrict__ aux) {
     constexpr int PER = 8;                           // consecutive block sums per thread
     __shared__ unsigned long long s_w[16];
     __shared__ unsigned long long s_carry;
@@ -390,6 +392,8 @@ __global__ __launch_bounds__(1024) void k_chunk_scan(GsxFrameCtl* __restrict__ c
         const uint32_t take = take64 < win ? static_cast<uint32_t>(take64) : win;
         ctl->n_blocks = s_fit;
         ctl->pairs = s_pairs;
+        aux[0] = cur;                                   // for k_raster, off the control block's line
+        aux[1] = m;
         ctl->cursor[iter + 1] = cur + take;
         const uint32_t tp = ctl->total_pairs;
         ctl->total_pairs = (tp + s_pairs < tp) ? 0xFFFFFFFFu : tp + s_pairs;
@@ -472,7 +476,7 @@ __global__ __launch_bounds__(GSX_RASTER_NT) void k_raster(const uint32_t* __rest
                                                           const float4* __restrict__ rank_rec, uint32_t iter, GsxViewParams vp, uint32_t first,
                                                           uint32_t* __restrict__ tile_state, uint32_t* __restrict__ live_bits,
                                                           float4* __restrict__ accum, GsxFrameCtl* __restrict__ ctl,
-                                                          uint8_t* __restrict__ fb) {
+                                                          uint32_t* __restrict__ aux, uint8_t* __restrict__ fb) {
     constexpr uint32_t NW = GSX_RASTER_NT / 64;                   // 2 waves = 2 halves
     static_assert(GSX_RASTER_BATCH == GSX_RASTER_NT, "one staged splat per thread");
     __shared__ float4 s_a[GSX_RASTER_BATCH];  // cx cy ex ey
@@ -504,12 +508,14 @@ __global__ __launch_bounds__(GSX_RASTER_NT) void k_raster(const uint32_t* __rest
         cr = gsx_f2{a0.x, a1.x}; cg = gsx_f2{a0.y, a1.y}; cb = gsx_f2{a0.z, a1.z}; T = gsx_f2{a0.w, a1.w};
     }
     const float cut = vp.cut;
-    const uint32_t rank_hi = MODE == 2 ? ctl->m - ctl->cursor[iter] : 0u;
+    const uint32_t rank_hi = MODE == 2 ? aux[1] - aux[0] : 0u;   // m - cursor, read off the control block's hot line
     // pixel-centre rectangle of half 0; half w is offset by 8 rows
     const float tx0f = static_cast<float>(tx * GSX_TILE_W) + 0.5f, ty0f = static_cast<float>(ty * GSX_TILE_H) + 0.5f;
     // near -> far: this iteration's list of the tile is already in that order
+    uint32_t lo_done = begin;                          // end of the last batch this tile consumed
     for (uint32_t lo = begin; lo < end;) {
         const uint32_t nb = min(static_cast<uint32_t>(GSX_RASTER_BATCH), end - lo);
+        lo_done = lo + nb;
         __syncthreads();  // previous batch fully consumed
         if (tid == 0) s_live[0] = 0;
         // stage: thread j gathers splat j of the batch and tests its quad against the two 16x8 halves
@@ -617,6 +623,9 @@ __global__ __launch_bounds__(GSX_RASTER_NT) void k_raster(const uint32_t* __rest
         tile_state[tile] = 2u;
         atomicAnd(&live_bits[tty * ((vp.tiles_x + 31u) / 32u) + (ttx >> 5)], ~(1u << (ttx & 31u)));
         atomicSub(&ctl->live_tiles, 1u);
+        // how deep (in ranks from the near end) this tile had to look: next frame's schedule is sized from the maximum
+        // (aux lives on its own cache lines, see gsx_internal.h)
+        if (lo_done > begin) atomicMax(&aux[16], aux[0] + pair_val[lo_done - 1] + 1u);
     }
     // the framebuffer always holds the composite of everything drawn so far over the clear colour
     uint32_t* row = reinterpret_cast<uint32_t*>(fb) + static_cast<uint64_t>(py) * static_cast<uint32_t>(vp.width);
@@ -681,7 +690,7 @@ static int launch_iteration(gsx_ctx* c, uint32_t iter, uint32_t window, bool fir
     if (nb > 0) {
         hipLaunchKernelGGL(k_chunk_count, dim3(nb), dim3(GSX_BIN_NT), 0, c->stream, c->ctl, iter, window, sorted, c->geo,
                            c->live_bits, vp, c->scan_block_sums, c->sub_off, c->rank_box, c->rank_rec);
-        hipLaunchKernelGGL(k_chunk_scan, dim3(1), dim3(1024), 0, c->stream, c->ctl, iter, window, nb, c->scan_block_sums, budget);
+        hipLaunchKernelGGL(k_chunk_scan, dim3(1), dim3(1024), 0, c->stream, c->ctl, iter, window, nb, c->scan_block_sums, budget, c->aux);
         const uint32_t waves = nb * GSX_BIN_SUBS;                       // one per 64-rank sub-block, capped
         const uint32_t emit_grid = gsx_div_up(waves, GSX_BIN_NT / 64) < 4096u ? gsx_div_up(waves, GSX_BIN_NT / 64) : 4096u;
         hipLaunchKernelGGL(k_chunk_emit, dim3(emit_grid), dim3(GSX_BIN_NT), 0, c->stream, c->ctl, iter, vp.tiles_x,
@@ -714,13 +723,13 @@ static int launch_iteration(gsx_ctx* c, uint32_t iter, uint32_t window, bool fir
     const uint32_t fi = first ? 1u : 0u;
     if (f.mode == 0)
         hipLaunchKernelGGL(k_raster<0>, dim3(f.n_tiles), dim3(GSX_RASTER_NT), 0, c->stream, c->tile_start, c->pair_val[cur], c->rank_rec, iter, vp,
-                           fi, c->tile_state, c->live_bits, c->accum, c->ctl, c->fb);
+                           fi, c->tile_state, c->live_bits, c->accum, c->ctl, c->aux, c->fb);
     else if (f.mode == 1)
         hipLaunchKernelGGL(k_raster<1>, dim3(f.n_tiles), dim3(GSX_RASTER_NT), 0, c->stream, c->tile_start, c->pair_val[cur], c->rank_rec, iter, vp,
-                           fi, c->tile_state, c->live_bits, c->accum, c->ctl, c->fb);
+                           fi, c->tile_state, c->live_bits, c->accum, c->ctl, c->aux, c->fb);
     else
         hipLaunchKernelGGL(k_raster<2>, dim3(f.n_tiles), dim3(GSX_RASTER_NT), 0, c->stream, c->tile_start, c->pair_val[cur], c->rank_rec, iter, vp,
-                           fi, c->tile_state, c->live_bits, c->accum, c->ctl, c->fb);
+                           fi, c->tile_state, c->live_bits, c->accum, c->ctl, c->aux, c->fb);
     if (c->profiling && iter < GSX_MAX_SCHED && !f.continuing) GSX_HIP(c, hipEventRecord(c->ev[EV_IT0 + 2 * iter + 1], c->stream));
     return GSX_OK;
 }
@@ -792,17 +801,17 @@ int gsx_launch_render(gsx_ctx* c, const gsx_uniforms* u, uint32_t w, uint32_t h,
     // (K3, the projection, runs inside k_chunk_count on the ranks each iteration reaches)
     if (c->profiling) GSX_HIP(c, hipEventRecord(c->ev[EV_PROJ0], c->stream));
     hipLaunchKernelGGL(k_frame_init, dim3(gsx_div_up(n_tiles, 256)), dim3(256), 0, c->stream, c->ctl, c->m_dev, c->live_bits,
-                       c->tile_state, vp.tiles_x, vp.tiles_y);
+                       c->tile_state, vp.tiles_x, vp.tiles_y, c->aux);
     if (c->profiling) GSX_HIP(c, hipEventRecord(c->ev[EV_PROJ1], c->stream));
 
     // K4 + K5: near -> far iterations with geometrically growing rank windows.  Only as many ranks are scheduled
-    // as recent frames needed before every tile was retired (+25 %): what lies behind is hidden anyway, and if this
+    // as recent frames needed before every tile was retired (+12 %): what lies behind is hidden anyway, and if this
     // frame does need more, gsx_frame_finish runs the rest (correct, just not pre-queued).
     uint64_t need = c->need_pos ? 0 : ~0u;
     for (uint32_t k = 0; k < 8 && k < c->need_pos; ++k) need = c->need_hist[k] > need ? c->need_hist[k] : need;
     if (need > m_cap) need = m_cap;
     c->frame.need_base = static_cast<uint32_t>(need);
-    need = need + need / 4 + 65536;
+    need = need + need / 8 + 32768;
     if (need > m_cap || c->opt_no_history) need = m_cap;
     uint32_t n_iters = 0;
     uint64_t covered = 0;
@@ -818,6 +827,7 @@ int gsx_launch_render(gsx_ctx* c, const gsx_uniforms* u, uint32_t w, uint32_t h,
     } while (covered < need);
     f.n_iters = n_iters;
     GSX_HIP(c, hipMemcpyAsync(c->ctl_host, c->ctl, sizeof(GsxFrameCtl), hipMemcpyDeviceToHost, c->stream));
+    GSX_HIP(c, hipMemcpyAsync(c->aux_host, c->aux, 128, hipMemcpyDeviceToHost, c->stream));
     GSX_HIP(c, hipEventRecord(c->frame_ev, c->stream));
     c->frame_pending = true;
     if (c->profiling) GSX_HIP(c, hipEventRecord(c->ev[EV_RAST1], c->stream));
@@ -858,6 +868,7 @@ int gsx_frame_finish(gsx_ctx* c) {
         GSX_HIP(c, hipMemcpyAsync(&c->ctl->stall, &zero, 4, hipMemcpyHostToDevice, c->stream));
         if ((rc = launch_iteration(c, 0, h.m - cur, false)) != GSX_OK) { c->frame_pending = false; return rc; }
         GSX_HIP(c, hipMemcpyAsync(c->ctl_host, c->ctl, sizeof(GsxFrameCtl), hipMemcpyDeviceToHost, c->stream));
+        GSX_HIP(c, hipMemcpyAsync(c->aux_host, c->aux, 128, hipMemcpyDeviceToHost, c->stream));
         GSX_HIP(c, hipStreamSynchronize(c->stream));
         last = 1;
     }
@@ -866,8 +877,8 @@ int gsx_frame_finish(gsx_ctx* c) {
         // by the end of the queued iterations) what the schedule was based on, else everything
         const GsxFrameCtl& h = *c->ctl_host;
         uint32_t rec = ~0u;
-        if (h.dead_at) rec = h.dead_at - 1u;
-        else if (h.live_tiles == 0u) rec = h.cursor[last] < f.need_base ? h.cursor[last] : f.need_base;
+        if (h.live_tiles == 0u) rec = c->aux_host[16];    // every tile retired: the deepest rank any of them consumed
+        else if (h.dead_at) rec = h.dead_at - 1u;
         c->need_hist[c->need_pos++ % 8u] = rec;
     }
     c->tim.tile_pairs = c->ctl_host->total_pairs;
