@@ -282,3 +282,24 @@ def test_large_overlap_4k_bands(gsx_fresh, pkg, oracle, synth):
     for b in range(8):                                   # 270-row bands as in SURVEY 8(d): boundaries inside tiles
         gsx.render(u, w, h, b * 270, (b + 1) * 270, out=ragged)
     assert np.abs(ragged.astype(np.int32) - img.astype(np.int32)).max() <= 1
+
+
+def test_20m_scene_properties(gsx_fresh, pkg, oracle, synth):
+    """cfg-4 size (20M splats): sort and frame loop at the largest configured scene, by properties."""
+    gsx = gsx_fresh
+    n, w, h = 20_000_000, 1920, 1080
+    splats = oracle.raw_to_splat(synth.clustered_cloud(n, seed=20))
+    gsx.upload(splats)
+    for steps in (0, 3):
+        view, proj, cam = camera(oracle, w, h, steps)
+        perm = gsx.sort(cam)
+        k = oracle.distance_keys(splats, cam)[perm]
+        assert np.all(k[:-1] >= k[1:])                                   # sortedness
+        same = k[1:] == k[:-1]
+        assert np.all(perm[1:][same] > perm[:-1][same])                  # ties by ascending index
+        assert np.array_equal(np.bincount(perm, minlength=n), np.ones(n, np.int64))   # a permutation
+        u = pkg.make_uniforms(proj, view)
+        img = gsx.render(u, w, h)
+        assert np.all(img[..., 3] == 255) and img[..., :3].std() > 10
+        assert np.array_equal(gsx.render(u, w, h), img) or np.abs(gsx.render(u, w, h).astype(np.int32) - img.astype(np.int32)).max() <= 1
+    del splats
