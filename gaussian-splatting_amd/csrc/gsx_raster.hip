@@ -7,20 +7,18 @@
 // blend, no depth buffer (main.cpp:338-344,359) and the (0.05,0.05,0.05,1) clear
 // (renderer.cpp:162-164).
 //
-// Design: vs_main runs ONCE per splat (the reference runs it 4x, once per quad
-// vertex) in original splat order with coalesced SoA loads and leaves a 32-B
-// screen-space record.  Because every quad is a view-plane-parallel
-// parallelogram at constant clip w, uv is an affine function of the pixel
-// position, so coverage + uv come from one 2x2 inverse instead of triangle
-// setup.  The binner expands the depth-sorted permutation into (tile, splat)
-// pairs in rank order and a stable 2-pass radix sort by tile id (the same radix
-// passes as the depth sort) yields per-tile lists that preserve depth order.
-// The rasterizer composites each 16x16 tile in sorted order, walking the list
-// from the NEAR end with a transmittance accumulator
+// Design: the frame is drawn in a few near -> far iterations over the depth-sorted
+// permutation.  Per iteration: project the window's splats (vs_main ONCE per splat, the reference runs it
+// 4x, once per quad vertex; gathered by rank from 64-byte scene records) and count their tiles, skipping
+// splats whose tile box holds no unsaturated tile; scan; emit (tile, splat) pairs in near -> far order;
+// stable 2-pass radix sort by tile id (the depth sort's kernels), which keeps depth order inside each tile;
+// composite.  Because every quad is a view-plane-parallel parallelogram at constant clip w, uv is an affine
+// function of the pixel position, so coverage + uv come from one 2x2 inverse instead of triangle setup.
+// The rasterizer composites each 16x16 tile front to back with a transmittance accumulator
 //     C = sum_i c_i a_i prod_{j nearer than i} (1 - a_j)  +  T_final * clear
-// which is algebraically the reference's far-to-near "over" blend and lets a
-// tile stop as soon as every pixel's transmittance is below 2^-11 (bounded
-// error < 0.13/255).
+// which is algebraically the reference's far-to-near "over" blend and lets a tile retire as soon as every
+// pixel's transmittance is below 2^-11 (bounded error < 0.13/255); retired tiles are never binned, sorted
+// or shaded again, and splats behind the last needed rank are never even projected.
 #include <cstddef>
 #include <cstdio>
 #include <cstdlib>
