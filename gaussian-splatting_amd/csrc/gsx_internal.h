@@ -175,6 +175,7 @@ struct gsx_ctx {
     // ranks (from the near end) earlier frames needed before every tile was retired; ~0u = the whole selection
     uint32_t need_hist[8] = {};
     uint32_t need_pos = 0;             // frames recorded so far (ring position = need_pos % 8)
+    float density0 = 0.0f;             // (tile, splat) pairs per rank in the last frame's first window (0 = unknown)
     hipEvent_t frame_ev = nullptr;
     bool frame_pending = false;
     // tuning (gsx_set_option); 0 = automatic

@@ -261,59 +261,86 @@ __global__ __launch_bounds__(GSX_BIN_NT) void k_chunk_count(const GsxFrameCtl* _
     }
 }
 
-// K4b.  One WAVE per 64-rank sub-block of the blocks that fit the budget: its pairs go to
-// [block offset + sub offset, ...) in near -> far order.  The wave reads what k_chunk_count left per rank,
-// scans the 64 counts, and writes the pairs cooperatively (coalesced stores; every slot finds its rank by
-// binary search in the 65 offsets held in the wave's own LDS slice).  No workgroup barrier anywhere.
-__global__ __launch_bounds__(GSX_BIN_NT) void k_chunk_emit(const GsxFrameCtl* __restrict__ ctl, uint32_t iter, uint32_t tiles_x,
+// K4b.  Pair emission, parallel over PAIR SLOTS: wave W writes slots [W*S, (W+1)*S) of the iteration's pair array
+// (S = GSX_EMIT_SLICE), whatever ranks they belong to, so a window of few huge splats (thousands of tiles each)
+// spreads over the chip like a window of many small ones.  The wave finds its first 1024-rank block with a
+// 64-ary search over the scanned block offsets, then walks 64-rank sub-blocks: it reads the tile boxes
+// k_chunk_count left per rank, scans the 64 counts, and writes its part of the sub-block's pairs (near -> far)
+// with coalesced stores; every slot finds its rank by binary search in the 65 offsets held in the wave's own
+// LDS slice.  No workgroup barrier anywhere.
+#ifndef GSX_EMIT_SLICE
+#define GSX_EMIT_SLICE 512u
+#endif
+__global__ __launch_bounds__(GSX_BIN_NT) void k_chunk_emit(const GsxFrameCtl* __restrict__ ctl, uint32_t tiles_x,
                                                            const uint32_t* __restrict__ block_sums, const uint32_t* __restrict__ sub_off,
                                                            const uint32_t* __restrict__ rank_box,
                                                            uint16_t* __restrict__ pair_key, uint32_t* __restrict__ pair_val) {
     constexpr uint32_t SUB = GSX_BIN_TILE / GSX_BIN_SUBS;        // 64 ranks
     constexpr uint32_t NW = GSX_BIN_NT / 64;
-    static_assert(SUB == 64, "one rank per lane");
-    __shared__ uint32_t s_off[NW][SUB + 1], s_box[NW][SUB], s_pay[NW][SUB];
+    static_assert(SUB == 64 && GSX_BIN_SUBS == 16, "one rank per lane, 17 sub offsets per block");
+    __shared__ uint32_t s_off[NW][SUB + 1], s_box[NW][SUB];
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const uint32_t n_items = ctl->n_blocks * GSX_BIN_SUBS;       // sub-blocks of the blocks that fit the budget
+    const uint32_t total = ctl->pairs, nbk = ctl->n_blocks;
     uint32_t* off = s_off[wave];
     uint32_t* sbx = s_box[wave];
-    uint32_t* spy = s_pay[wave];
-    // the grid is capped (a frame's last windows are mostly hidden): every wave strides over sub-blocks
-    for (uint32_t item = blockIdx.x * NW + wave; item < n_items; item += gridDim.x * NW) {
-        const uint32_t b = item / GSX_BIN_SUBS, sb = item % GSX_BIN_SUBS;
-        const uint32_t* so = sub_off + b * (GSX_BIN_SUBS + 1) + sb;
-        const uint32_t sub_base = so[0], sub_total = so[1] - so[0];
-        if (sub_total == 0u) continue;                           // wave-uniform
-        const uint32_t local = b * GSX_BIN_TILE + sb * SUB + lane;
-        const uint32_t box = rank_box[local];
-        const uint32_t pay = local;                              // the pair names the splat by its rank inside the window
-        const uint32_t cnt = box == GSX_RBOX_NONE ? 0u : (((box >> 16) & 0xFFu) + 1u) * ((box >> 24) + 1u);
-        uint32_t incl = cnt;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t t = __shfl_up(incl, o);
-            if (lane >= static_cast<uint32_t>(o)) incl += t;
+    for (uint64_t w = blockIdx.x * NW + wave; w * GSX_EMIT_SLICE < total; w += static_cast<uint64_t>(gridDim.x) * NW) {
+        const uint32_t s0 = static_cast<uint32_t>(w * GSX_EMIT_SLICE);
+        const uint32_t s1 = (total - s0 < GSX_EMIT_SLICE) ? total : s0 + GSX_EMIT_SLICE;
+        // largest b with block_sums[b] <= s0 (block_sums[0] == 0; empty blocks share their successor's offset)
+        uint32_t lo = 0, hi = nbk;
+        while (hi - lo > 1u) {
+            const uint32_t step = (hi - lo + 63u) / 64u;
+            const uint32_t idx = lo + lane * step;
+            const uint32_t v = idx < hi ? block_sums[idx] : 0xFFFFFFFFu;
+            const uint32_t c = static_cast<uint32_t>(__popcll(__builtin_amdgcn_ballot_w64(v <= s0)));   // >= 1
+            lo += (c - 1u) * step;
+            hi = (lo + step < hi) ? lo + step : hi;
         }
-        __builtin_amdgcn_wave_barrier();                         // previous item's LDS reads are done (same wave, in order)
-        off[lane] = incl - cnt;
-        sbx[lane] = box;
-        spy[lane] = pay;
-        if (lane == 63) off[64] = incl;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const uint32_t base = block_sums[b] + sub_base;   // block offsets were scanned by k_chunk_scan; fits the buffers by construction
-        for (uint32_t slot = lane; slot < sub_total; slot += 64) {
-            uint32_t lo = 0;                              // last q with off[q] <= slot (skips empty ranks)
+        uint32_t cur = s0;
+        for (uint32_t b = lo; b < nbk && cur < s1; ++b) {
+            const uint32_t bbase = block_sums[b];
+            const uint32_t so = lane <= GSX_BIN_SUBS ? sub_off[b * (GSX_BIN_SUBS + 1) + lane] : 0xFFFFFFFFu;
+            const uint32_t blk_total = __shfl(so, GSX_BIN_SUBS);
+            if (bbase + blk_total <= cur) continue;               // an empty block (wave-uniform)
+            if (bbase >= s1) break;
+            // first sub-block that ends behind `cur`: number of inner boundaries so[1..16] at or before it
+            uint32_t sb = static_cast<uint32_t>(__popcll(__builtin_amdgcn_ballot_w64(lane >= 1u && lane <= GSX_BIN_SUBS && bbase + so <= cur)));
+            for (; sb < GSX_BIN_SUBS && cur < s1; ++sb) {
+                const uint32_t sub_base = bbase + __shfl(so, sb), sub_end = bbase + __shfl(so, sb + 1u);
+                if (sub_end <= cur) continue;                     // empty sub-block
+                if (sub_base >= s1) { cur = s1; break; }
+                const uint32_t local = b * GSX_BIN_TILE + sb * SUB + lane;
+                const uint32_t box = rank_box[local];
+                const uint32_t cnt = box == GSX_RBOX_NONE ? 0u : (((box >> 16) & 0xFFu) + 1u) * ((box >> 24) + 1u);
+                uint32_t incl = cnt;
 #pragma unroll
-            for (uint32_t step = 32; step >= 1; step >>= 1)
-                if (off[lo + step] <= slot) lo += step;
-            const uint32_t rel = slot - off[lo], bx = sbx[lo];
-            const uint32_t wx = ((bx >> 16) & 0xFFu) + 1u;
-            const uint32_t dy = rel / wx, dx = rel - dy * wx;
-            const uint32_t tx = (bx & 0xFFu) + dx, ty = ((bx >> 8) & 0xFFu) + dy;
-            pair_key[base + slot] = static_cast<uint16_t>(ty * tiles_x + tx);
-            pair_val[base + slot] = spy[lo];
+                for (int o = 1; o < 64; o <<= 1) {
+                    const uint32_t t = __shfl_up(incl, o);
+                    if (lane >= static_cast<uint32_t>(o)) incl += t;
+                }
+                __builtin_amdgcn_wave_barrier();                 // previous sub-block's LDS reads are done (same wave, in order)
+                off[lane] = incl - cnt;
+                sbx[lane] = box;
+                if (lane == 63) off[64] = incl;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const uint32_t from = (cur > sub_base ? cur : sub_base) - sub_base;
+                const uint32_t to = (s1 < sub_end ? s1 : sub_end) - sub_base;
+                for (uint32_t slot = from + lane; slot < to; slot += 64) {
+                    uint32_t q = 0;                               // last q with off[q] <= slot (skips empty ranks)
+#pragma unroll
+                    for (uint32_t step = 32; step >= 1; step >>= 1)
+                        if (off[q + step] <= slot) q += step;
+                    const uint32_t rel = slot - off[q], bx = sbx[q];
+                    const uint32_t wx = ((bx >> 16) & 0xFFu) + 1u;
+                    const uint32_t dy = rel / wx, dx = rel - dy * wx;
+                    const uint32_t tx = (bx & 0xFFu) + dx, ty = ((bx >> 8) & 0xFFu) + dy;
+                    pair_key[sub_base + slot] = static_cast<uint16_t>(ty * tiles_x + tx);
+                    pair_val[sub_base + slot] = b * GSX_BIN_TILE + sb * SUB + q;   // the splat's rank inside the window
+                }
+                cur = sub_base + to;
+            }
         }
     }
 }
@@ -392,6 +419,7 @@ __global__ __launch_bounds__(1024) void k_chunk_scan(GsxFrameCtl* __restrict__ c
         ctl->pairs = s_pairs;
         aux[0] = cur;                                   // for k_raster, off the control block's line
         aux[1] = m;
+        if (iter == 0u && cur == 0u) { aux[2] = s_pairs; aux[3] = take; }   // density of the nearest window, for the host's schedule
         ctl->cursor[iter + 1] = cur + take;
         const uint32_t tp = ctl->total_pairs;
         ctl->total_pairs = (tp + s_pairs < tp) ? 0xFFFFFFFFu : tp + s_pairs;
@@ -689,20 +717,21 @@ static int launch_iteration(gsx_ctx* c, uint32_t iter, uint32_t window, bool fir
         hipLaunchKernelGGL(k_chunk_count, dim3(nb), dim3(GSX_BIN_NT), 0, c->stream, c->ctl, iter, window, sorted, c->geo,
                            c->live_bits, vp, c->scan_block_sums, c->sub_off, c->rank_box, c->rank_rec);
         hipLaunchKernelGGL(k_chunk_scan, dim3(1), dim3(1024), 0, c->stream, c->ctl, iter, window, nb, c->scan_block_sums, budget, c->aux);
-        const uint32_t waves = nb * GSX_BIN_SUBS;                       // one per 64-rank sub-block, capped
-        const uint32_t emit_grid = gsx_div_up(waves, GSX_BIN_NT / 64) < 4096u ? gsx_div_up(waves, GSX_BIN_NT / 64) : 4096u;
-        hipLaunchKernelGGL(k_chunk_emit, dim3(emit_grid), dim3(GSX_BIN_NT), 0, c->stream, c->ctl, iter, vp.tiles_x,
-                           c->scan_block_sums, c->sub_off, c->rank_box, c->pair_key[0], c->pair_val[0]);
+        // slot-parallel: one wave per GSX_EMIT_SLICE pairs.  The pair count is only known on the device (a window of a few
+        // thousand huge splats can fill the whole budget), so the grid is sized for the budget; surplus waves exit at once.
+        uint32_t emit_grid = gsx_div_up(gsx_div_up(c->pair_cap, GSX_EMIT_SLICE), GSX_BIN_NT / 64);
+        if (emit_grid > 4096u) emit_grid = 4096u;
+        if (emit_grid < 1u) emit_grid = 1u;
+        hipLaunchKernelGGL(k_chunk_emit, dim3(emit_grid), dim3(GSX_BIN_NT), 0, c->stream, c->ctl, vp.tiles_x, c->scan_block_sums,
+                           c->sub_off, c->rank_box, c->pair_key[0], c->pair_val[0]);
     }
     // stable sort of the iteration's pairs by tile id; the pair count stays on the device
     const uint32_t* count_ptr = &c->ctl->pairs;
     uint32_t tile_bits = 1;
     while ((1u << tile_bits) < f.n_tiles) ++tile_bits;
     const GsxRadixPlan plan = gsx_radix_plan(tile_bits);
-    // grid: one round of resident workgroups, but no more blocks than the window could ever fill
-    uint64_t expect = static_cast<uint64_t>(window) * 16u;
-    if (expect > c->pair_cap) expect = c->pair_cap;
-    const uint32_t g = gsx_radix_blocks(expect, GSX_PAIR_TILE, c->pair_slots);
+    // grid: one round of resident workgroups (sized for the budget: the pair count is device-side)
+    const uint32_t g = gsx_radix_blocks(c->pair_cap, GSX_PAIR_TILE, c->pair_slots);
     uint32_t* cnt = c->pair_ws;
     uint32_t* totals = cnt + static_cast<uint64_t>(GSX_RADIX_MAX_DIGITS) * g;
     int cur = 0;
@@ -813,7 +842,15 @@ int gsx_launch_render(gsx_ctx* c, const gsx_uniforms* u, uint32_t w, uint32_t h,
     if (need > m_cap || c->opt_no_history) need = m_cap;
     uint32_t n_iters = 0;
     uint64_t covered = 0;
+    // first window: 256 K ranks, fewer when the nearest splats are large on screen (history: pairs per rank of the last
+    // frame's first window), so that the first iteration stays near 8 M pairs
     uint64_t win = c->opt_chunk_first ? c->opt_chunk_first : (256u << 10);
+    if (!c->opt_chunk_first && !c->opt_no_history && c->density0 > 0.0f) {
+        uint64_t wd = static_cast<uint64_t>(8.0e6f / c->density0);
+        wd = (wd + 1023u) / 1024u * 1024u;
+        if (wd < 2048u) wd = 2048u;
+        if (wd < win) win = wd;
+    }
     const uint64_t growth = c->opt_chunk_growth ? c->opt_chunk_growth : 4u;
     do {
         uint64_t wnd = win;
@@ -840,6 +877,7 @@ int gsx_frame_finish(gsx_ctx* c) {
     GSX_HIP(c, hipEventSynchronize(c->frame_ev));
     GsxFrameState& f = c->frame;
     uint32_t last = f.n_iters;
+    c->density0 = c->aux_host[3] >= 1024u ? static_cast<float>(c->aux_host[2]) / static_cast<float>(c->aux_host[3]) : 0.0f;
     static const bool trace = std::getenv("GSX_TRACE") != nullptr;
     for (int guard = 0; ; ++guard) {
         const GsxFrameCtl& h = *c->ctl_host;
