@@ -172,19 +172,31 @@ __global__ __launch_bounds__(256) void k_frame_init(GsxFrameCtl* __restrict__ ct
     for (uint32_t i = gtid; i < n_tiles; i += gsz) tile_state[i] = 0u;
 }
 
-// true if any tile of the inclusive box is still live; s_live = bit rows of `lw` words
-__device__ __forceinline__ bool gsx_box_live(const uint32_t* s_live, uint32_t lw, uint32_t tx0, uint32_t tx1, uint32_t ty0,
-                                             uint32_t ty1) {
+// true if any tile of the inclusive box is still live.  s_live = one row of GSX_LIVE_ROW_WORDS (8) words per tile
+// row in LDS (16-byte aligned).  Four rows are fetched per step with 16-byte reads and tested against per-word column
+// masks, so a splat covering a thousand tiles of a mostly retired frame costs ~35 dependent steps, not ~1000.
+__device__ __forceinline__ bool gsx_box_live(const uint32_t* s_live, uint32_t tx0, uint32_t tx1, uint32_t ty0, uint32_t ty1) {
     const uint32_t w0 = tx0 >> 5, w1 = tx1 >> 5;
     const uint32_t first = 0xFFFFFFFFu << (tx0 & 31u), last = 0xFFFFFFFFu >> (31u - (tx1 & 31u));
-    for (uint32_t ty = ty0; ty <= ty1; ++ty) {
-        const uint32_t* row = s_live + ty * lw;
-        for (uint32_t w = w0; w <= w1; ++w) {
-            uint32_t mask = 0xFFFFFFFFu;
-            if (w == w0) mask &= first;
-            if (w == w1) mask &= last;
-            if (row[w] & mask) return true;
+    uint32_t cm[GSX_LIVE_ROW_WORDS];
+#pragma unroll
+    for (uint32_t w = 0; w < GSX_LIVE_ROW_WORDS; ++w) {
+        uint32_t m = (w >= w0 && w <= w1) ? 0xFFFFFFFFu : 0u;
+        if (w == w0) m &= first;
+        if (w == w1) m &= last;
+        cm[w] = m;
+    }
+    const uint4* rows = reinterpret_cast<const uint4*>(s_live);
+    for (uint32_t ty = ty0; ty <= ty1; ty += 4u) {
+        uint32_t acc = 0u;
+#pragma unroll
+        for (uint32_t r = 0; r < 4u; ++r) {
+            const uint32_t y = (ty + r <= ty1) ? ty + r : ty1;      // (repeats the last row instead of branching)
+            const uint4 lo = rows[y * 2u], hi = rows[y * 2u + 1u];
+            acc |= (lo.x & cm[0]) | (lo.y & cm[1]) | (lo.z & cm[2]) | (lo.w & cm[3]) | (hi.x & cm[4]) | (hi.y & cm[5]) | (hi.z & cm[6]) |
+                   (hi.w & cm[7]);
         }
+        if (acc) return true;
     }
     return false;
 }
@@ -193,10 +205,10 @@ __device__ __forceinline__ bool gsx_box_live(const uint32_t* s_live, uint32_t lw
 // splat is culled or every tile of the box is retired).
 #define GSX_RBOX_NONE 0xFFFFFFFFu   // not a valid box: tx0 + (w-1) <= 255 always
 __device__ __forceinline__ uint32_t gsx_rank_pairs(const float4 p, const float4 ca, const float4 cb, const GsxViewParams& vp,
-                                                   const uint32_t* s_live, uint32_t lw, uint32_t& box, float4& a, float4& mm) {
+                                                   const uint32_t* s_live, uint32_t& box, float4& a, float4& mm) {
     if (!gsx_project(p, ca, cb, vp, a, mm)) return 0u;
     uint32_t tx0, tx1, ty0, ty1;
-    if (!gsx_tile_bbox(a, vp, tx0, tx1, ty0, ty1) || !gsx_box_live(s_live, lw, tx0, tx1, ty0, ty1)) return 0u;
+    if (!gsx_tile_bbox(a, vp, tx0, tx1, ty0, ty1) || !gsx_box_live(s_live, tx0, tx1, ty0, ty1)) return 0u;
     box = tx0 | (ty0 << 8) | ((tx1 - tx0) << 16) | ((ty1 - ty0) << 24);
     return (tx1 - tx0 + 1u) * (ty1 - ty0 + 1u);
 }
@@ -211,7 +223,7 @@ __global__ __launch_bounds__(GSX_BIN_NT) void k_chunk_count(const GsxFrameCtl* _
                                                             uint32_t* __restrict__ rank_box, float4* __restrict__ rank_rec) {
     const uint32_t tiles_x = vp.tiles_x, tiles_y = vp.tiles_y;
     __shared__ uint32_t s_tmp[GSX_BIN_NT / 64];
-    __shared__ uint32_t s_live[GSX_MAX_TILES_Y * GSX_LIVE_ROW_WORDS];
+    __shared__ __attribute__((aligned(16))) uint32_t s_live[GSX_MAX_TILES_Y * GSX_LIVE_ROW_WORDS];
     const uint32_t b = blockIdx.x;
     const uint32_t cur = ctl->cursor[iter], m = ctl->m;
     const uint32_t remaining = m - cur, win = window < remaining ? window : remaining;
@@ -221,7 +233,10 @@ __global__ __launch_bounds__(GSX_BIN_NT) void k_chunk_count(const GsxFrameCtl* _
         return;
     }
     const uint32_t lw = (tiles_x + 31u) / 32u;
-    for (uint32_t i = threadIdx.x; i < lw * tiles_y; i += GSX_BIN_NT) s_live[i] = live_bits[i];
+    for (uint32_t i = threadIdx.x; i < GSX_LIVE_ROW_WORDS * tiles_y; i += GSX_BIN_NT) {      // rows padded to 8 words
+        const uint32_t ty = i / GSX_LIVE_ROW_WORDS, w = i % GSX_LIVE_ROW_WORDS;
+        s_live[i] = w < lw ? live_bits[ty * lw + w] : 0u;
+    }
     __syncthreads();
     uint32_t tot = 0;
     const uint32_t local0 = b * GSX_BIN_TILE + threadIdx.x * GSX_BIN_IPT;
@@ -240,7 +255,7 @@ __global__ __launch_bounds__(GSX_BIN_NT) void k_chunk_count(const GsxFrameCtl* _
         rb[j] = GSX_RBOX_NONE;
         float4 a, mm;
         const float4 col = gc[j];
-        const uint32_t cnt = (local0 + j < win) ? gsx_rank_pairs(gp[j], ga[j], gb[j], vp, s_live, lw, rb[j], a, mm) : 0u;
+        const uint32_t cnt = (local0 + j < win) ? gsx_rank_pairs(gp[j], ga[j], gb[j], vp, s_live, rb[j], a, mm) : 0u;
         if (cnt) {
             // the 48-B screen-space record the rasterizer stages, in window-rank order
             float4* rec = rank_rec + static_cast<uint64_t>(local0 + j) * 3;
