@@ -847,13 +847,19 @@ int gsx_launch_render(gsx_ctx* c, const gsx_uniforms* u, uint32_t w, uint32_t h,
     if (c->profiling) GSX_HIP(c, hipEventRecord(c->ev[EV_PROJ1], c->stream));
 
     // K4 + K5: near -> far iterations with geometrically growing rank windows.  Only as many ranks are scheduled
-    // as recent frames needed before every tile was retired (+12 %): what lies behind is hidden anyway, and if this
+    // as recent frames needed before every tile was retired (plus a margin): what lies behind is hidden anyway, and if this
     // frame does need more, gsx_frame_finish runs the rest (correct, just not pre-queued).
     uint64_t need = c->need_pos ? 0 : ~0u;
     for (uint32_t k = 0; k < 8 && k < c->need_pos; ++k) need = c->need_hist[k] > need ? c->need_hist[k] : need;
     if (need > m_cap) need = m_cap;
     c->frame.need_base = static_cast<uint32_t>(need);
-    need = need + need / 8 + 32768;
+    {   // margin: 12 % plus a quarter of the depth again (at least 2 K, at most 32 K ranks) — a fixed 32 K margin
+        // would queue a whole dead iteration behind a dense foreground that saturates within ~15 K ranks
+        uint64_t pad = need / 4;
+        if (pad < 2048u) pad = 2048u;
+        if (pad > 32768u) pad = 32768u;
+        need = need + need / 8 + pad;
+    }
     if (need > m_cap || c->opt_no_history) need = m_cap;
     uint32_t n_iters = 0;
     uint64_t covered = 0;
