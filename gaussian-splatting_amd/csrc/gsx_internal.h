@@ -12,14 +12,14 @@
 
 // ---- sort geometry: one workgroup sorts one tile of NT*IPT keys per pass ----
 #ifndef GSX_SORT_NT
-#define GSX_SORT_NT 256
+#define GSX_SORT_NT 512
 #endif
 #ifndef GSX_SORT_IPT
 #define GSX_SORT_IPT 12
 #endif
 #define GSX_SORT_TILE (GSX_SORT_NT * GSX_SORT_IPT)
-#define GSX_PAIR_NT 256
-#define GSX_PAIR_IPT 16
+#define GSX_PAIR_NT 512
+#define GSX_PAIR_IPT 12
 #define GSX_PAIR_TILE (GSX_PAIR_NT * GSX_PAIR_IPT)
 
 // ---- raster geometry ----

@@ -108,6 +108,14 @@ __device__ __forceinline__ void gsx_block_range(uint32_t count, uint32_t g, uint
     end = static_cast<uint32_t>(lo + per < count ? lo + per : count);
 }
 
+// Number of column ranges a pass over `count` keys uses: one per tile while that is at most `max_cols` (= two rounds
+// of resident workgroups), else max_cols / 2 longer ranges (one per resident workgroup).  Every kernel of a pass
+// derives it from the same device-side count, so the count matrix stride always agrees.
+__host__ __device__ __forceinline__ uint32_t gsx_n_cols(uint32_t count, uint32_t tile, uint32_t max_cols) {
+    const uint32_t t = (count + tile - 1u) / tile;
+    return t < 1u ? 1u : (t > max_cols ? (max_cols / 2u > 0u ? max_cols / 2u : 1u) : t);
+}
+
 // Contention-tolerant LDS digit histogram: GSX_HREP interleaved copies, lane l uses copy
 // l % GSX_HREP, so even a constant digit is only an 8-way conflict.
 #define GSX_HREP 8
@@ -118,52 +126,60 @@ __device__ __forceinline__ void gsx_hist_zero(uint32_t* s_hist, int nt) {
 __device__ __forceinline__ void gsx_hist_add(uint32_t* s_hist, uint32_t d) {
     atomicAdd(&s_hist[d * GSX_HREP + (threadIdx.x & (GSX_HREP - 1))], 1u);
 }
-__device__ __forceinline__ void gsx_hist_store(const uint32_t* s_hist, uint32_t nd, int nt, uint32_t* __restrict__ cnt) {
+__device__ __forceinline__ void gsx_hist_store(const uint32_t* s_hist, uint32_t nd, int nt, uint32_t* __restrict__ cnt, uint32_t n_cols,
+                                               uint32_t col) {
     __syncthreads();
-    const uint32_t col = gsx_logical_block();
     for (uint32_t d = threadIdx.x; d < nd; d += nt) {
         uint32_t acc = 0;
 #pragma unroll
         for (int r = 0; r < GSX_HREP; ++r) acc += s_hist[d * GSX_HREP + r];
-        cnt[static_cast<uint64_t>(d) * gridDim.x + col] = acc;
+        cnt[static_cast<uint64_t>(d) * n_cols + col] = acc;
     }
 }
 
-// ---- H: digit counts of each block's range -> cnt[d * G + b] -----------------
+// ---- H: digit counts of each column range -> cnt[d * n_cols + col] (block b: columns b, b + G, ...) -------
 template <typename KeyT, int NT>
 __global__ __launch_bounds__(NT) void k_radix_hist(const KeyT* __restrict__ keys, const uint32_t* __restrict__ count_ptr,
-                                                   uint32_t shift, uint32_t bits, uint32_t* __restrict__ cnt) {
+                                                   uint32_t shift, uint32_t bits, uint32_t* __restrict__ cnt, uint32_t tile,
+                                                   uint32_t max_cols) {
     __shared__ uint32_t s_hist[GSX_RADIX_MAX_DIGITS * GSX_HREP];
     const uint32_t nd = 1u << bits, mask = nd - 1u;
-    gsx_hist_zero(s_hist, NT);
-    uint32_t begin, end;
-    gsx_block_range(*count_ptr, gridDim.x, gsx_logical_block(), begin, end);
-    constexpr int VEC = 16 / sizeof(KeyT);          // keys per 16-byte load; ranges start 16-byte aligned
-    using VecT = uint4;
-    const uint32_t n_vec = (end - begin) / VEC;
-    const VecT* kv = reinterpret_cast<const VecT*>(keys + begin);
-    for (uint32_t i = threadIdx.x; i < n_vec; i += NT) {
-        const VecT v = kv[i];
-        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    const uint32_t count = *count_ptr;
+    const uint32_t n_cols = gsx_n_cols(count, tile, max_cols);
+    for (uint32_t col = gsx_logical_block(); col < n_cols; col += gridDim.x) {
+        gsx_hist_zero(s_hist, NT);
+        uint32_t begin, end;
+        gsx_block_range(count, n_cols, col, begin, end);
+        constexpr int VEC = 16 / sizeof(KeyT);          // keys per 16-byte load; ranges start 16-byte aligned
+        using VecT = uint4;
+        const uint32_t n_vec = (end - begin) / VEC;
+        const VecT* kv = reinterpret_cast<const VecT*>(keys + begin);
+        for (uint32_t i = threadIdx.x; i < n_vec; i += NT) {
+            const VecT v = kv[i];
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            if (sizeof(KeyT) == 4) {
-                gsx_hist_add(s_hist, (w[j] >> shift) & mask);
-            } else {
-                gsx_hist_add(s_hist, ((w[j] & 0xFFFFu) >> shift) & mask);
-                gsx_hist_add(s_hist, ((w[j] >> 16) >> shift) & mask);
+            for (int j = 0; j < 4; ++j) {
+                if (sizeof(KeyT) == 4) {
+                    gsx_hist_add(s_hist, (w[j] >> shift) & mask);
+                } else {
+                    gsx_hist_add(s_hist, ((w[j] & 0xFFFFu) >> shift) & mask);
+                    gsx_hist_add(s_hist, ((w[j] >> 16) >> shift) & mask);
+                }
             }
         }
+        for (uint32_t g = begin + n_vec * VEC + threadIdx.x; g < end; g += NT)
+            gsx_hist_add(s_hist, (static_cast<uint32_t>(keys[g]) >> shift) & mask);
+        gsx_hist_store(s_hist, nd, NT, cnt, n_cols, col);
+        __syncthreads();
     }
-    for (uint32_t g = begin + n_vec * VEC + threadIdx.x; g < end; g += NT)
-        gsx_hist_add(s_hist, (static_cast<uint32_t>(keys[g]) >> shift) & mask);
-    gsx_hist_store(s_hist, nd, NT, cnt);
 }
 
 // ---- S: per digit, exclusive scan over blocks (in place) + digit total --------
 template <int DUMMY>
-__global__ __launch_bounds__(256) void k_radix_scan(uint32_t* __restrict__ cnt, uint32_t g, uint32_t* __restrict__ totals) {
+__global__ __launch_bounds__(256) void k_radix_scan(uint32_t* __restrict__ cnt, const uint32_t* __restrict__ count_ptr, uint32_t tile,
+                                                   uint32_t max_cols, uint32_t* __restrict__ totals) {
     __shared__ uint32_t s_tmp[4];
+    const uint32_t g = gsx_n_cols(*count_ptr, tile, max_cols);
     uint32_t* row = cnt + static_cast<uint64_t>(blockIdx.x) * g;
     constexpr int PER = GSX_RADIX_MAX_BLOCKS / 256;   // 8 consecutive entries per thread
     uint32_t v[PER], sum = 0;
@@ -185,30 +201,60 @@ __global__ __launch_bounds__(256) void k_radix_scan(uint32_t* __restrict__ cnt, 
 }
 
 // ---- X: rank + scatter ---------------------------------------------------------
+// The keys are dealt to `n_cols` contiguous column ranges (one count column each); block b works on columns
+// b, b + G, b + 2G, ... (b = logical, XCD-contiguous index).  At any moment the workgroups of one XCD therefore
+// write neighbouring columns, whose runs for a digit are adjacent in memory, and that XCD's L2 merges them into
+// whole lines before they leave the chip (measured: 100 MB -> 52 MB written per 6 M-key pass against one
+// two-tile range per block).  The next tile's keys are requested before the current tile is written out.
 template <typename KeyT, int NT, int IPT, bool IOTA_VALS>
-__global__ __launch_bounds__(NT) void k_radix_scatter(const KeyT* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_radix_scatter(const KeyT* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                                                       KeyT* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
                                                       const uint32_t* __restrict__ count_ptr, uint32_t shift, uint32_t bits,
-                                                      const uint32_t* __restrict__ cnt_scanned, const uint32_t* __restrict__ totals) {
+                                                      const uint32_t* __restrict__ cnt_scanned, const uint32_t* __restrict__ totals,
+                                                      uint32_t max_cols) {
     constexpr int NW = NT / 64;
     constexpr int TILE = NT * IPT;
     __shared__ KeyT s_keys[TILE];
     __shared__ uint32_t s_vals[TILE];
     __shared__ uint32_t s_whist[NW][GSX_RADIX_MAX_DIGITS];   // per-wave digit counts, then wave prefixes + bin base
     __shared__ uint32_t s_gofs[GSX_RADIX_MAX_DIGITS];        // global index = s_gofs[d] + LDS slot
-    __shared__ uint32_t s_run[GSX_RADIX_MAX_DIGITS];         // next free global slot of digit d for this block
     __shared__ uint32_t s_tmp[NW];
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t nd = 1u << bits, mask = nd - 1u;
     const uint32_t count = *count_ptr;
+    const uint32_t n_cols = gsx_n_cols(count, NT * IPT, max_cols);
+    uint32_t col = gsx_logical_block();
     uint32_t rbegin, rend;
-    gsx_block_range(count, gridDim.x, gsx_logical_block(), rbegin, rend);
+    if (col >= n_cols) return;
+    gsx_block_range(count, n_cols, col, rbegin, rend);
     if (rbegin >= rend) return;
+    uint32_t tile_base = rbegin;
 
-    // running offsets: exclusive scan of the digit totals + this block's scanned count.
-    // Thread t owns the PER consecutive digits t*PER .. t*PER+PER-1.
-    constexpr int PER = GSX_RADIX_MAX_DIGITS / NT;
-    static_assert(PER >= 1 && PER * NT == GSX_RADIX_MAX_DIGITS, "NT must divide the digit count");
+    // Thread t owns the PER consecutive digits t*PER .. t*PER+PER-1: their bases (exclusive scan of the digit
+    // totals), the column's scanned counts and the running output offsets stay in its registers.
+    constexpr int PER = GSX_RADIX_MAX_DIGITS / NT > 0 ? GSX_RADIX_MAX_DIGITS / NT : 1;   // (threads past the last digit own none)
+    static_assert(PER * NT >= GSX_RADIX_MAX_DIGITS, "every digit needs an owner");
+    KeyT key[IPT];
+    uint32_t val[IPT];
+    uint32_t col_cnt[PER], base[PER], run[PER];
+    auto request = [&](uint32_t tb, uint32_t re) {     // wave-striped: item i of lane l = wave_base + i*64 + l
+        const uint32_t wave_base = tb + wave * (64 * IPT);
+#pragma unroll
+        for (int i = 0; i < IPT; ++i) {
+            const uint32_t g = wave_base + i * 64 + lane;
+            key[i] = (g < re) ? keys_in[g] : static_cast<KeyT>(~static_cast<KeyT>(0));
+            val[i] = IOTA_VALS ? g : ((g < re) ? vals_in[g] : 0u);
+        }
+    };
+    auto request_col = [&](uint32_t c) {
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            const uint32_t d = tid * PER + j;
+            col_cnt[j] = (d < nd) ? cnt_scanned[static_cast<uint64_t>(d) * n_cols + c] : 0u;
+        }
+    };
+    request(tile_base, rend);
+    request_col(col);
     {
         uint32_t tot[PER], sum = 0;
 #pragma unroll
@@ -217,47 +263,31 @@ __global__ __launch_bounds__(NT) void k_radix_scatter(const KeyT* __restrict__ k
             tot[j] = (d < nd) ? totals[d] : 0u;
             sum += tot[j];
         }
-        uint32_t run = gsx_block_excl_scan<NT>(sum, s_tmp, nullptr);
+        uint32_t acc = gsx_block_excl_scan<NT>(sum, s_tmp, nullptr);
 #pragma unroll
-        for (int j = 0; j < PER; ++j) {
-            const uint32_t d = tid * PER + j;
-            if (d < nd) s_run[d] = run + cnt_scanned[static_cast<uint64_t>(d) * gridDim.x + gsx_logical_block()];
-            run += tot[j];
-        }
+        for (int j = 0; j < PER; ++j) { base[j] = acc; acc += tot[j]; }
     }
-    __syncthreads();
+    bool new_col = true;
 
-    for (uint32_t tile_base = rbegin; tile_base < rend; tile_base += TILE) {
-        const uint32_t wave_base = tile_base + wave * (64 * IPT);
-        // ---- load keys and values together (wave-striped: item i of lane l = wave_base + i*64 + l) ----
-        KeyT key[IPT];
-        uint32_t val[IPT];
-#pragma unroll
-        for (int i = 0; i < IPT; ++i) {
-            const uint32_t g = wave_base + i * 64 + lane;
-            key[i] = (g < rend) ? keys_in[g] : static_cast<KeyT>(~static_cast<KeyT>(0));
-            val[i] = IOTA_VALS ? g : ((g < rend) ? vals_in[g] : 0u);
-        }
+    for (;;) {
         for (uint32_t t = tid; t < NW * GSX_RADIX_MAX_DIGITS; t += NT) (&s_whist[0][0])[t] = 0;
         __syncthreads();   // also: previous tile's write-out has finished reading s_keys/s_vals/s_gofs
 
         // ---- rank inside the wave: ballots + one returning LDS add per (item, digit) ----
         uint32_t* wh = s_whist[wave];
-        uint32_t lead_prev[IPT];
-        uint16_t lower[IPT];
-        uint8_t leader[IPT];
+        uint32_t lead_prev[IPT], pk[IPT];   // pk = lanes below with the same digit | leader lane << 16
 #pragma unroll
         for (int i = 0; i < IPT; ++i) {
             const uint32_t d = (static_cast<uint32_t>(key[i]) >> shift) & mask;
             const uint64_t peers = gsx_match_digit(d, bits);
-            lower[i] = static_cast<uint16_t>(gsx_mbcnt(peers));
-            leader[i] = static_cast<uint8_t>(__builtin_ctzll(peers));
+            const uint32_t lower = gsx_mbcnt(peers);
+            pk[i] = lower | (static_cast<uint32_t>(__builtin_ctzll(peers)) << 16);
             lead_prev[i] = 0;
-            if (lower[i] == 0) lead_prev[i] = atomicAdd(&wh[d], static_cast<uint32_t>(__popcll(peers)));
+            if (lower == 0) lead_prev[i] = atomicAdd(&wh[d], static_cast<uint32_t>(__popcll(peers)));
         }
-        uint16_t rank[IPT];
+        uint32_t rank[IPT];
 #pragma unroll
-        for (int i = 0; i < IPT; ++i) rank[i] = static_cast<uint16_t>(__shfl(lead_prev[i], leader[i]) + lower[i]);
+        for (int i = 0; i < IPT; ++i) rank[i] = static_cast<uint32_t>(__shfl(lead_prev[i], pk[i] >> 16)) + (pk[i] & 0xFFFFu);
         __syncthreads();
 
         // ---- per digit: prefix over waves, bin base, global offset ----
@@ -272,6 +302,7 @@ __global__ __launch_bounds__(NT) void k_radix_scatter(const KeyT* __restrict__ k
                     for (int w = 0; w < NW; ++w) acc[j] += s_whist[w][d];
                 }
                 sum += acc[j];
+                if (new_col) run[j] = base[j] + col_cnt[j];
             }
             uint32_t bin_base = gsx_block_excl_scan<NT>(sum, s_tmp, nullptr);
 #pragma unroll
@@ -285,8 +316,8 @@ __global__ __launch_bounds__(NT) void k_radix_scatter(const KeyT* __restrict__ k
                         s_whist[w][d] = pre;       // bin base + counts of the lower waves
                         pre += c;
                     }
-                    s_gofs[d] = s_run[d] - bin_base;
-                    s_run[d] += acc[j];
+                    s_gofs[d] = run[j] - bin_base;
+                    run[j] += acc[j];
                 }
                 bin_base += acc[j];
             }
@@ -301,10 +332,29 @@ __global__ __launch_bounds__(NT) void k_radix_scatter(const KeyT* __restrict__ k
             s_keys[pos] = key[i];
             s_vals[pos] = val[i];
         }
+        const uint32_t valid = (rend - tile_base < static_cast<uint32_t>(TILE)) ? (rend - tile_base) : TILE;
+
+        // ---- next tile (of this column, else the block's next column): request its keys now ----
+        bool more = true;
+        tile_base += TILE;
+        new_col = false;
+        if (tile_base >= rend) {
+            col += gridDim.x;
+            new_col = true;
+            more = col < n_cols;
+            if (more) {
+                gsx_block_range(count, n_cols, col, rbegin, rend);
+                tile_base = rbegin;
+                more = rbegin < rend;
+            }
+        }
+        if (more) {
+            request(tile_base, rend);
+            if (new_col) request_col(col);
+        }
         __syncthreads();
 
         // ---- write-out: consecutive LDS slots of one digit are consecutive in HBM ----
-        const uint32_t valid = (rend - tile_base < static_cast<uint32_t>(TILE)) ? (rend - tile_base) : TILE;
 #pragma unroll
         for (int i = 0; i < IPT; ++i) {
             const uint32_t p = i * NT + tid;
@@ -316,6 +366,7 @@ __global__ __launch_bounds__(NT) void k_radix_scatter(const KeyT* __restrict__ k
                 vals_out[dst] = s_vals[p];
             }
         }
+        if (!more) break;
     }
 }
 
@@ -342,6 +393,13 @@ static inline GsxRadixPlan gsx_radix_plan(uint32_t total_bits) {
     return p;
 }
 
+// Upper bound of the column ranges of a sort (gsx_n_cols): two rounds of `slots` resident workgroups.
+static inline uint32_t gsx_radix_columns(uint32_t slots) {
+    uint32_t t = 2u * slots;
+    if (t < 2u) t = 2u;
+    if (t > GSX_RADIX_MAX_BLOCKS) t = GSX_RADIX_MAX_BLOCKS;
+    return t;
+}
 // Grid of a sort of up to `cap` keys: one round of resident workgroups (`slots`), but never
 // more blocks than tiles.
 static inline uint32_t gsx_radix_blocks(uint64_t cap, uint32_t tile, uint32_t slots) {
@@ -351,7 +409,7 @@ static inline uint32_t gsx_radix_blocks(uint64_t cap, uint32_t tile, uint32_t sl
     if (t > GSX_RADIX_MAX_BLOCKS) t = GSX_RADIX_MAX_BLOCKS;
     return static_cast<uint32_t>(t);
 }
-// bytes of the count matrix + totals for one sort of up to `cap` keys
+// words of the count matrix + totals for one sort with up to `blocks` column ranges
 static inline uint64_t gsx_radix_workspace_words(uint32_t blocks) {
     return static_cast<uint64_t>(GSX_RADIX_MAX_DIGITS) * blocks + GSX_RADIX_MAX_DIGITS;
 }

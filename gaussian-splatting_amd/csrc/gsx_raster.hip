@@ -717,8 +717,7 @@ static int ensure_pairs(gsx_ctx* c, uint64_t budget) {
         c->pair_alloc = budget;
     }
     c->pair_cap = budget;
-    const uint32_t g_max = gsx_radix_blocks(c->pair_cap, GSX_PAIR_TILE, c->pair_slots);
-    return ensure(c, &c->pair_ws, &c->pair_ws_words, gsx_radix_workspace_words(g_max));
+    return ensure(c, &c->pair_ws, &c->pair_ws_words, gsx_radix_workspace_words(GSX_RADIX_MAX_BLOCKS));
 }
 
 // One iteration of the frame loop: window of `window` ranks behind cursor[iter].
@@ -747,16 +746,18 @@ static int launch_iteration(gsx_ctx* c, uint32_t iter, uint32_t window, bool fir
     const GsxRadixPlan plan = gsx_radix_plan(tile_bits);
     // grid: one round of resident workgroups (sized for the budget: the pair count is device-side)
     const uint32_t g = gsx_radix_blocks(c->pair_cap, GSX_PAIR_TILE, c->pair_slots);
+    const uint32_t cols = gsx_radix_columns(c->pair_slots);
     uint32_t* cnt = c->pair_ws;
-    uint32_t* totals = cnt + static_cast<uint64_t>(GSX_RADIX_MAX_DIGITS) * g;
+    uint32_t* totals = cnt + static_cast<uint64_t>(GSX_RADIX_MAX_DIGITS) * cols;
     int cur = 0;
     for (int p = 0; p < plan.n_passes; ++p) {
         hipLaunchKernelGGL((k_radix_hist<uint16_t, GSX_PAIR_NT>), dim3(g), dim3(GSX_PAIR_NT), 0, c->stream, c->pair_key[cur],
-                           count_ptr, plan.shift[p], plan.bits[p], cnt);
-        hipLaunchKernelGGL((k_radix_scan<0>), dim3(1u << plan.bits[p]), dim3(256), 0, c->stream, cnt, g, totals);
+                           count_ptr, plan.shift[p], plan.bits[p], cnt, static_cast<uint32_t>(GSX_PAIR_TILE), cols);
+        hipLaunchKernelGGL((k_radix_scan<0>), dim3(1u << plan.bits[p]), dim3(256), 0, c->stream, cnt, count_ptr,
+                           static_cast<uint32_t>(GSX_PAIR_TILE), cols, totals);
         hipLaunchKernelGGL((k_radix_scatter<uint16_t, GSX_PAIR_NT, GSX_PAIR_IPT, false>), dim3(g), dim3(GSX_PAIR_NT), 0, c->stream,
                            c->pair_key[cur], c->pair_val[cur], c->pair_key[cur ^ 1], c->pair_val[cur ^ 1], count_ptr, plan.shift[p],
-                           plan.bits[p], cnt, totals);
+                           plan.bits[p], cnt, totals, cols);
         cur ^= 1;
     }
     hipLaunchKernelGGL(k_tile_ranges, dim3(gsx_div_up(f.n_tiles + 1, 256)), dim3(256), 0, c->stream, c->pair_key[cur], count_ptr,

@@ -67,13 +67,16 @@ template <bool IOTA>
 __global__ __launch_bounds__(GSX_SORT_NT) void k_keygen_hist0(const float4* __restrict__ pos4, const uint32_t* __restrict__ sel,
                                                               const uint32_t* __restrict__ m_ptr, float cx, float cy, float cz,
                                                               uint32_t key_lo, uint32_t key_span, uint32_t shift, uint32_t bits,
-                                                              uint32_t* __restrict__ keys, uint32_t* __restrict__ cnt,
+                                                              uint32_t* __restrict__ keys, uint32_t* __restrict__ cnt, uint32_t max_cols,
                                                               GsxDevFlags* __restrict__ flags) {
     __shared__ uint32_t s_hist[GSX_RADIX_MAX_DIGITS * GSX_HREP];
     const uint32_t nd = 1u << bits, mask = nd - 1u;
+    const uint32_t m = *m_ptr;
+    const uint32_t n_cols = gsx_n_cols(m, GSX_SORT_TILE, max_cols);
+    for (uint32_t col = gsx_logical_block(); col < n_cols; col += gridDim.x) {
     gsx_hist_zero(s_hist, GSX_SORT_NT);
     uint32_t begin, end;
-    gsx_block_range(*m_ptr, gridDim.x, gsx_logical_block(), begin, end);
+    gsx_block_range(m, n_cols, col, begin, end);
     constexpr int UNROLL = 4;
     for (uint32_t base = begin + threadIdx.x; base < end; base += GSX_SORT_NT * UNROLL) {
         float4 p[UNROLL];
@@ -98,7 +101,9 @@ __global__ __launch_bounds__(GSX_SORT_NT) void k_keygen_hist0(const float4* __re
             gsx_hist_add(s_hist, (rel >> shift) & mask);
         }
     }
-    gsx_hist_store(s_hist, nd, GSX_SORT_NT, cnt);
+    gsx_hist_store(s_hist, nd, GSX_SORT_NT, cnt, n_cols, col);
+    __syncthreads();
+    }
 }
 
 // Distances only (parity aid for gsx_get_keys).
@@ -181,27 +186,29 @@ static void key_bounds(const gsx_ctx* c, uint32_t* key_lo, uint32_t* key_span) {
 
 template <typename KeyT, int NT, int IPT>
 static void launch_pass(gsx_ctx* c, hipStream_t st, uint32_t g, const KeyT* kin, const uint32_t* vin, KeyT* kout, uint32_t* vout,
-                        const uint32_t* count_ptr, uint32_t shift, uint32_t bits, uint32_t* ws, bool need_hist, bool iota,
-                        int ev_pass /* -1 = no events */) {
+                        const uint32_t* count_ptr, uint32_t shift, uint32_t bits, uint32_t* ws, uint32_t cols, bool need_hist,
+                        bool iota, int ev_pass /* -1 = no events */) {
+    constexpr uint32_t TILE = NT * IPT;
     uint32_t* cnt = ws;
-    uint32_t* totals = ws + static_cast<uint64_t>(GSX_RADIX_MAX_DIGITS) * g;
+    uint32_t* totals = ws + static_cast<uint64_t>(GSX_RADIX_MAX_DIGITS) * cols;
     if (need_hist)
-        hipLaunchKernelGGL((k_radix_hist<KeyT, NT>), dim3(g), dim3(NT), 0, st, kin, count_ptr, shift, bits, cnt);
-    hipLaunchKernelGGL((k_radix_scan<0>), dim3(1u << bits), dim3(256), 0, st, cnt, g, totals);
+        hipLaunchKernelGGL((k_radix_hist<KeyT, NT>), dim3(g), dim3(NT), 0, st, kin, count_ptr, shift, bits, cnt, TILE, cols);
+    hipLaunchKernelGGL((k_radix_scan<0>), dim3(1u << bits), dim3(256), 0, st, cnt, count_ptr, TILE, cols, totals);
     if (ev_pass >= 0) (void)hipEventRecord(c->ev[EV_X0 + 2 * ev_pass], st);
     if (iota)
         hipLaunchKernelGGL((k_radix_scatter<KeyT, NT, IPT, true>), dim3(g), dim3(NT), 0, st, kin, vin, kout, vout, count_ptr, shift,
-                           bits, cnt, totals);
+                           bits, cnt, totals, cols);
     else
         hipLaunchKernelGGL((k_radix_scatter<KeyT, NT, IPT, false>), dim3(g), dim3(NT), 0, st, kin, vin, kout, vout, count_ptr, shift,
-                           bits, cnt, totals);
+                           bits, cnt, totals, cols);
     if (ev_pass >= 0) (void)hipEventRecord(c->ev[EV_X0 + 2 * ev_pass + 1], st);
 }
 
 int gsx_launch_sort(gsx_ctx* c) {
     const uint32_t cap = c->m_cap;
     const uint32_t g = gsx_radix_blocks(cap, GSX_SORT_TILE, c->sort_slots);
-    if (gsx_radix_workspace_words(g) > c->sort_ws_words) { c->err = "sort workspace too small"; return GSX_E_INTERNAL; }
+    const uint32_t cols = gsx_radix_columns(c->sort_slots);
+    if (gsx_radix_workspace_words(cols) > c->sort_ws_words) { c->err = "sort workspace too small"; return GSX_E_INTERNAL; }
     uint32_t key_lo, key_span;
     key_bounds(c, &key_lo, &key_span);
     uint32_t total_bits = 0;
@@ -210,10 +217,10 @@ int gsx_launch_sort(gsx_ctx* c) {
     if (c->profiling) GSX_HIP(c, hipEventRecord(c->ev[EV_KEY0], c->stream));
     if (c->sel_iota)
         hipLaunchKernelGGL(k_keygen_hist0<true>, dim3(g), dim3(GSX_SORT_NT), 0, c->stream, c->pos4, nullptr, c->m_dev, c->cam[0],
-                           c->cam[1], c->cam[2], key_lo, key_span, plan.shift[0], plan.bits[0], c->keys[0], c->sort_ws, c->flags);
+                           c->cam[1], c->cam[2], key_lo, key_span, plan.shift[0], plan.bits[0], c->keys[0], c->sort_ws, cols, c->flags);
     else
         hipLaunchKernelGGL(k_keygen_hist0<false>, dim3(g), dim3(GSX_SORT_NT), 0, c->stream, c->pos4, c->sel_idx, c->m_dev, c->cam[0],
-                           c->cam[1], c->cam[2], key_lo, key_span, plan.shift[0], plan.bits[0], c->keys[0], c->sort_ws, c->flags);
+                           c->cam[1], c->cam[2], key_lo, key_span, plan.shift[0], plan.bits[0], c->keys[0], c->sort_ws, cols, c->flags);
     if (c->profiling) GSX_HIP(c, hipEventRecord(c->ev[EV_KEY1], c->stream));
     uint32_t cur = 0;
     c->sampled_pass = (c->prof_level == 2 && plan.n_passes > 0) ? static_cast<int>(c->prof_frame % static_cast<uint32_t>(plan.n_passes)) : -1;
@@ -221,7 +228,7 @@ int gsx_launch_sort(gsx_ctx* c) {
     for (int p = 0; p < plan.n_passes; ++p) {
         const bool first = p == 0;
         launch_pass<uint32_t, GSX_SORT_NT, GSX_SORT_IPT>(c, c->stream, g, c->keys[cur], first ? c->sel_idx : c->vals[cur], c->keys[cur ^ 1],
-                                                          c->vals[cur ^ 1], c->m_dev, plan.shift[p], plan.bits[p], c->sort_ws,
+                                                          c->vals[cur ^ 1], c->m_dev, plan.shift[p], plan.bits[p], c->sort_ws, cols,
                                                           /*need_hist=*/!first, /*iota=*/first && c->sel_iota,
                                                           (c->profiling || c->sampled_pass == p) ? p : -1);
         cur ^= 1;
@@ -246,7 +253,7 @@ int gsx_launch_keys_only(gsx_ctx* c, float* dist_dev) {
     return GSX_OK;
 }
 
-uint64_t gsx_sort_workspace_words(uint64_t cap) { return gsx_radix_workspace_words(gsx_radix_blocks(cap, GSX_SORT_TILE, GSX_RADIX_MAX_BLOCKS)); }
+uint64_t gsx_sort_workspace_words(uint64_t) { return gsx_radix_workspace_words(GSX_RADIX_MAX_BLOCKS); }
 
 // Resident workgroups of the depth sort's scatter kernel on this device (CUs x blocks per CU).
 uint32_t gsx_sort_slots(int cus) {
