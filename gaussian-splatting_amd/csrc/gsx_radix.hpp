@@ -1,13 +1,14 @@
 // gsx_radix.hpp — stable LSD radix sort of (key, u32 value) pairs for gfx950,
 // as three kernels per digit pass:
 //
-//   H  k_radix_hist     every block counts the digits of ITS contiguous key range
-//                       (replicated LDS atomics, 16-byte loads)
+//   H  k_radix_hist     digit counts of every column range (contiguous keys, one per tile
+//                       while that fits two rounds of workgroups); block b takes columns
+//                       b, b + G, ... (replicated LDS atomics, 16-byte loads)
 //   S  k_radix_scan     one block per digit: exclusive scan of that digit's counts
-//                       over blocks (+ the digit's total)
-//   X  k_radix_scatter  every block re-reads its range tile by tile, ranks the keys
-//                       with wave64 ballots, stages them through LDS in digit order
-//                       and writes them out; per-digit running offsets live in LDS
+//                       over columns (+ the digit's total)
+//   X  k_radix_scatter  the same column walk: ranks a tile's keys with wave64 ballots,
+//                       stages them through LDS in digit order and writes them out;
+//                       per-digit running offsets live in registers of the digit's owner
 //
 // Replaces the reference's std::sort(indices, distances[a] > distances[b])
 // (SplatMesh.h:97-108); the same passes order the binner's (tile, splat) pairs.
@@ -19,12 +20,12 @@
 // on 6M keys the look-back cost 25 us of a 66 us pass, and the whole pass is
 // latency- not bandwidth-bound.  Here no workgroup ever waits on another one: the
 // only cross-workgroup data is the small count matrix handed over at kernel
-// boundaries, a block's outputs for one digit are contiguous across its tiles
-// (long runs for the write combiner), and nothing can spin or hang.
+// boundaries, the workgroups of an XCD write neighbouring columns at the same time
+// (their partial lines merge in that XCD's L2), and nothing can spin or hang.
 //
 // Ranking uses no LDS read-modify-write chain: per item 8-9 ballots give the
 // peer mask, the lowest peer issues ONE returning ds_add, and results are
-// broadcast afterwards, so the 12-16 items of a thread are in flight together.
+// broadcast afterwards, so the 12 items of a thread are in flight together.
 #pragma once
 #include "gsx_internal.h"
 
@@ -279,7 +280,11 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 #pragma unroll
         for (int i = 0; i < IPT; ++i) {
             const uint32_t d = (static_cast<uint32_t>(key[i]) >> shift) & mask;
+#ifdef GSX_ABL_NORANK   // (GSX_ABL_*: ablation switches for tools/sortbench.hip, never defined in the library build)
+            const uint64_t peers = 1ull << lane;
+#else
             const uint64_t peers = gsx_match_digit(d, bits);
+#endif
             const uint32_t lower = gsx_mbcnt(peers);
             pk[i] = lower | (static_cast<uint32_t>(__builtin_ctzll(peers)) << 16);
             lead_prev[i] = 0;
@@ -361,9 +366,18 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             if (p < valid) {
                 const KeyT k = s_keys[p];
                 const uint32_t d = (static_cast<uint32_t>(k) >> shift) & mask;
+#ifdef GSX_ABL_LINWRITE
+                const uint32_t dst = tile_base - TILE + p + (s_gofs[d] == 0xFFFFFFFFu);
+#else
                 const uint32_t dst = s_gofs[d] + p;
+#endif
+#ifdef GSX_ABL_NOWRITE
+                if (k == static_cast<KeyT>(0x12345677u) && dst == 0x7FFFFFFFu)
+#endif
+                {
                 keys_out[dst] = k;
                 vals_out[dst] = s_vals[p];
+                }
             }
         }
         if (!more) break;

@@ -18,6 +18,6 @@ for name in sys.argv[1:] or ("clustered",):
     assert g.lib.gsx_debug_read(g.ctx, 8, a.ctypes.data_as(C.c_void_p), C.c_uint64(a.nbytes)) == 0
     d = a[18:].view(np.uint64)
     t = g.timings()
-    print(name, "pairs", t["tile_pairs"], "listed(tile visits)", d[3] // 4, "wave-splat shades", d[0], "hit lanes", d[1], "useful lanes", d[2],
-          "lane efficiency", d[1] / (64.0 * d[0]), "useful", d[2] / (64.0 * d[0]), "shades per listed pair", d[0] / (d[3] / 4))
+    print(name, "pairs", t["tile_pairs"], "listed(tile visits)", d[3] // 2, "wave-splat shades", d[0], "hit lanes", d[1], "useful lanes", d[2],
+          "lane efficiency", d[1] / (64.0 * d[0]), "useful", d[2] / (64.0 * d[0]), "shades per listed pair", d[0] / (d[3] / 2))
     g.close()
