@@ -157,21 +157,20 @@ def main():
         if dist is not None and not a.no_gather:
             gather()
     fence()
-    pass_ms, pass_n = {}, {}
-    pairs = iters = passes = 0
+    g.scatter_samples(reset=True)
+    # Frames are queued back to back (the next frame's sort is queued behind the running frame; gsx_render waits for
+    # the previous frame only to check whether it needs more iterations).  Nothing is read back inside the loop: the
+    # sampled scatter launches sit in the library's event ring and are collected after the closing fence.
     t0 = time.perf_counter()
     for i in range(a.steps):
         step(i)
         if dist is not None and not a.no_gather:
             gather()
-        t = g.timings()        # waits for the frame (like a present) and reads the sampled scatter launch
-        if t["scatter_sample"]:
-            p = t["scatter_sample"] - 1
-            pass_ms[p] = pass_ms.get(p, 0.0) + t["scatter_ms"]
-            pass_n[p] = pass_n.get(p, 0) + 1
-        pairs += t["tile_pairs"]; iters += t["render_iters"]; passes += t["sort_passes"]
     fence()
     elapsed = time.perf_counter() - t0
+    per_pass, pass_n = g.scatter_samples(reset=True)     # mean launch duration of each radix pass over the timed region
+    t = g.timings()
+    pairs = t["tile_pairs"] * a.steps; iters = t["render_iters"] * a.steps; passes = t["sort_passes"] * a.steps
     if dist is not None:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=torch.device("cuda", local_rank))
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -193,7 +192,6 @@ def main():
         K = a.steps
         n = a.splats
         passes_per_frame = passes / K
-        per_pass = {p: pass_ms[p] / pass_n[p] for p in pass_ms}          # mean launch duration of each radix pass
         launch_ms = sum(per_pass.values()) / max(len(per_pass), 1)       # average k_radix_scatter<u32> launch
         achieved = SCATTER_BYTES_PER_SPLAT * n / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
         keysort_ms = (acc["keygen_ms"] + acc["sort_ms"]) / n_prof

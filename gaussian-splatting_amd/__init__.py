@@ -20,7 +20,7 @@ GSX_OK, GSX_E_INVALID, GSX_E_HIP, GSX_E_NOMEM, GSX_E_STATE, GSX_E_UNSUPPORTED, G
 
 # every symbol include/gsx.h declares
 ABI_SYMBOLS = [
-    "gsx_create", "gsx_destroy", "gsx_last_error", "gsx_sync", "gsx_set_profiling", "gsx_get_timings", "gsx_set_option",
+    "gsx_create", "gsx_destroy", "gsx_last_error", "gsx_sync", "gsx_set_profiling", "gsx_get_timings", "gsx_get_scatter_samples", "gsx_set_option",
     "gsx_upload_splats", "gsx_upload_splats_dev", "gsx_select_all", "gsx_select_list", "gsx_set_lod_octree",
     "gsx_set_lod_hc", "gsx_select_octree", "gsx_select_hc", "gsx_get_selection", "gsx_sort", "gsx_get_sorted_dev",
     "gsx_get_keys", "gsx_render", "gsx_get_framebuffer_dev",
@@ -217,6 +217,13 @@ class Gsx:
     def set_option(self, name, value):
         """Tuning knob of the frame loop (include/gsx.h gsx_set_option): pair_budget, chunk_first, chunk_growth."""
         self._chk(self.lib.gsx_set_option(self.ctx, name.encode(), C.c_uint64(int(value))))
+
+    def scatter_samples(self, reset=True):
+        """Profiling level 2: ({pass: mean launch ms}, {pass: launches}) of the sampled depth-sort scatter launches."""
+        sums = (C.c_double * 4)()
+        cnt = (C.c_uint32 * 4)()
+        self._chk(self.lib.gsx_get_scatter_samples(self.ctx, sums, cnt, C.c_int(1 if reset else 0)))
+        return ({p: sums[p] / cnt[p] for p in range(4) if cnt[p]}, {p: int(cnt[p]) for p in range(4) if cnt[p]})
 
     def timings(self):
         t = Timings()

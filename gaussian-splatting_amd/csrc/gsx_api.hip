@@ -49,7 +49,7 @@ int alloc_scene(gsx_ctx* c, uint64_t n) {
     if ((rc = dev_alloc(c, &c->sel_idx, n))) return rc;
     c->sel_cap = n;
     for (int b = 0; b < 2; ++b)
-        if ((rc = dev_alloc(c, &c->keys[b], n)) || (rc = dev_alloc(c, &c->vals[b], n))) return rc;
+        if ((rc = dev_alloc(c, &c->keys[b], n)) || (rc = dev_alloc(c, &c->vals[b], n)) || (rc = dev_alloc(c, &c->perm[b], n))) return rc;
     c->sort_cap = n;
     c->sort_ws_words = gsx_sort_workspace_words(n);
     if ((rc = dev_alloc(c, &c->sort_ws, c->sort_ws_words))) return rc;
@@ -91,6 +91,10 @@ int gsx_create(int device, gsx_ctx** out) {
     for (int i = 0; i < EV_COUNT; ++i)
         if (hipEventCreate(&c->ev[i]) != hipSuccess) return fail(GSX_E_HIP);
     if (hipEventCreateWithFlags(&c->frame_ev, hipEventDisableTiming) != hipSuccess) return fail(GSX_E_HIP);
+    for (int i = 0; i < GSX_SAMPLE_RING; ++i) {
+        c->samp_pass[i] = -1;
+        if (hipEventCreate(&c->samp_ev[i][0]) != hipSuccess || hipEventCreate(&c->samp_ev[i][1]) != hipSuccess) return fail(GSX_E_HIP);
+    }
     if (hipMalloc(reinterpret_cast<void**>(&c->ctl), sizeof(GsxFrameCtl)) != hipSuccess) return fail(GSX_E_NOMEM);
     if (hipMalloc(reinterpret_cast<void**>(&c->aux), 128) != hipSuccess) return fail(GSX_E_NOMEM);
     if (hipHostMalloc(reinterpret_cast<void**>(&c->aux_host), 128, hipHostMallocDefault) != hipSuccess) return fail(GSX_E_NOMEM);
@@ -120,7 +124,7 @@ int gsx_destroy(gsx_ctx* c) {
     dev_free(&c->sel_idx); dev_free(&c->m_dev);
     dev_free(&c->lod_a); dev_free(&c->lod_b); dev_free(&c->lod_parent); dev_free(&c->lod_leaf);
     dev_free(&c->lod_stop); dev_free(&c->lod_emit); dev_free(&c->lod_block_sums);
-    for (int b = 0; b < 2; ++b) { dev_free(&c->keys[b]); dev_free(&c->vals[b]); dev_free(&c->pair_key[b]); dev_free(&c->pair_val[b]); }
+    for (int b = 0; b < 2; ++b) { dev_free(&c->keys[b]); dev_free(&c->vals[b]); dev_free(&c->perm[b]); dev_free(&c->pair_key[b]); dev_free(&c->pair_val[b]); }
     dev_free(&c->sort_ws); dev_free(&c->aabb_dev); dev_free(&c->flags); dev_free(&c->pair_ws);
     dev_free(&c->splat_ntiles); dev_free(&c->scan_block_sums);
     dev_free(&c->tile_start); dev_free(&c->pair_total_dev); dev_free(&c->fb);
@@ -129,6 +133,9 @@ int gsx_destroy(gsx_ctx* c) {
     if (c->aux_host) (void)hipHostFree(c->aux_host);
     dev_free(&c->aux);
     if (c->frame_ev) (void)hipEventDestroy(c->frame_ev);
+    for (int i = 0; i < GSX_SAMPLE_RING; ++i)
+        for (int k = 0; k < 2; ++k)
+            if (c->samp_ev[i][k]) (void)hipEventDestroy(c->samp_ev[i][k]);
     if (c->host_word) (void)hipHostFree(c->host_word);
     if (c->flags_host) (void)hipHostFree(c->flags_host);
     for (int i = 0; i < EV_COUNT; ++i)
@@ -174,6 +181,21 @@ int gsx_set_profiling(gsx_ctx* c, int enabled) {
     return GSX_OK;
 }
 
+int gsx_get_scatter_samples(gsx_ctx* c, double sum_ms[4], uint32_t launches[4], int reset) {
+    if (!c || !sum_ms || !launches) return GSX_E_INVALID;
+    int rc = set_device(c);
+    if (rc) return rc;
+    if ((rc = gsx_frame_finish(c))) return rc;
+    GSX_HIP(c, hipStreamSynchronize(c->stream));
+    for (uint32_t k = 0; k < GSX_SAMPLE_RING; ++k) gsx_sample_drain(c, (c->samp_pos + k) % GSX_SAMPLE_RING);
+    for (int p = 0; p < 4; ++p) {
+        sum_ms[p] = c->samp_sum_ms[p];
+        launches[p] = c->samp_n[p];
+        if (reset) { c->samp_sum_ms[p] = 0.0; c->samp_n[p] = 0; }
+    }
+    return GSX_OK;
+}
+
 int gsx_get_timings(gsx_ctx* c, gsx_timings* out) {
     if (!c || !out) return GSX_E_INVALID;
     int rc = set_device(c);
@@ -203,9 +225,12 @@ int gsx_get_timings(gsx_ctx* c, gsx_timings* out) {
         t.total_ms = t.select_ms + t.keygen_ms + t.sort_ms + t.project_ms + t.bin_ms + t.raster_ms;
     }
     t.scatter_sample = 0;
-    if (c->prof_level == 2 && c->sorted_valid && c->sampled_pass >= 0) {
-        t.scatter_ms = ev_ms(c, EV_X0 + 2 * c->sampled_pass, EV_X0 + 2 * c->sampled_pass + 1);
-        t.scatter_sample = static_cast<uint32_t>(c->sampled_pass) + 1u;
+    if (c->prof_level == 2) {
+        for (uint32_t k = 0; k < GSX_SAMPLE_RING; ++k) gsx_sample_drain(c, (c->samp_pos + k) % GSX_SAMPLE_RING);   // oldest first
+        if (c->sorted_valid && c->samp_last_pass >= 0) {
+            t.scatter_ms = c->samp_last_ms;                       // the latest sort's sampled launch
+            t.scatter_sample = static_cast<uint32_t>(c->samp_last_pass) + 1u;
+        }
     }
     if (c->sorted_valid) {
         t.sort_passes = c->sort_passes;
@@ -387,7 +412,9 @@ int gsx_sort(gsx_ctx* c, const float cam_pos[3], uint32_t* idx_out_host) {
     if (!c || !cam_pos) return GSX_E_INVALID;
     int rc = set_device(c);
     if (rc) return rc;
-    if ((rc = gsx_frame_finish(c))) return rc;   // the frame in flight still reads the last permutation
+    // A frame in flight reads perm[perm_cur]; this sort writes the other buffer, so it is queued behind that frame without
+    // waiting for it.  Only a frame that still draws from the target buffer (two sorts without a render between) must end first.
+    if (c->frame_pending && c->frame.sorted == c->perm[c->perm_cur ^ 1u] && (rc = gsx_frame_finish(c))) return rc;
     c->cam[0] = cam_pos[0]; c->cam[1] = cam_pos[1]; c->cam[2] = cam_pos[2];
     if ((rc = gsx_launch_sort(c))) return rc;
     c->ev_recorded[EV_SORT1] = c->profiling;
@@ -395,7 +422,7 @@ int gsx_sort(gsx_ctx* c, const float cam_pos[3], uint32_t* idx_out_host) {
         GSX_HIP(c, hipMemcpyAsync(c->host_word, c->m_dev, 4, hipMemcpyDeviceToHost, c->stream));
         if ((rc = check_flags(c))) return rc;
         const uint32_t m = *c->host_word;
-        if (m) GSX_HIP(c, hipMemcpy(idx_out_host, c->vals[c->sorted_buf], static_cast<uint64_t>(m) * 4, hipMemcpyDeviceToHost));
+        if (m) GSX_HIP(c, hipMemcpy(idx_out_host, c->perm[c->perm_cur], static_cast<uint64_t>(m) * 4, hipMemcpyDeviceToHost));
     }
     return GSX_OK;
 }
@@ -407,7 +434,7 @@ int gsx_get_sorted_dev(gsx_ctx* c, const uint32_t** idx_dev, uint32_t* m) {
     if (rc) return rc;
     GSX_HIP(c, hipMemcpyAsync(c->host_word, c->m_dev, 4, hipMemcpyDeviceToHost, c->stream));
     if ((rc = check_flags(c))) return rc;
-    *idx_dev = c->vals[c->sorted_buf];
+    *idx_dev = c->perm[c->perm_cur];
     *m = *c->host_word;
     return GSX_OK;
 }

@@ -9,6 +9,7 @@
 #include "../../include/gsx.h"
 
 #define GSX_WAVE 64
+#define GSX_SAMPLE_RING 32
 
 // ---- sort geometry: one workgroup sorts one tile of NT*IPT keys per pass ----
 #ifndef GSX_SORT_NT
@@ -56,6 +57,7 @@ struct GsxFrameState {
     uint32_t n_tiles = 0;
     uint32_t n_iters = 0;
     uint32_t need_base = 0;   // ranks the schedule was derived from (before the margin)
+    const uint32_t* sorted = nullptr;   // the permutation this frame draws (one of gsx_ctx::perm)
     bool continuing = false;
 };
 
@@ -93,6 +95,14 @@ struct gsx_ctx {
     int prof_level = 0;                // 0 off, 1 all stages, 2 sampled (one scatter launch per frame)
     uint32_t prof_frame = 0;           // sorts launched (rotates the sampled pass)
     int sampled_pass = -1;             // level 2: pass whose scatter launch carries events in the last sort
+    // level 2 samples: a ring of event pairs, so frames can be queued back to back and the durations collected later
+    hipEvent_t samp_ev[GSX_SAMPLE_RING][2] = {};
+    int samp_pass[GSX_SAMPLE_RING];    // pass a slot's events bracket, -1 = slot free
+    uint32_t samp_pos = 0;
+    double samp_sum_ms[4] = {0, 0, 0, 0};
+    uint32_t samp_n[4] = {0, 0, 0, 0};
+    float samp_last_ms = 0.0f;
+    int samp_last_pass = -1;
 
     // scene (SoA in HBM)
     uint64_t n = 0;
@@ -126,7 +136,11 @@ struct gsx_ctx {
     uint64_t sort_ws_words = 0;
     uint32_t* host_word = nullptr;     // pinned staging word(s) for small device->host reads
     bool sorted_valid = false;
-    uint32_t sorted_buf = 0;           // vals[sorted_buf] holds the permutation
+    // The last radix pass writes into perm[perm_cur ^ 1] and then flips perm_cur: a frame still in flight (and any
+    // continuation iterations gsx_frame_finish queues for it later) keeps reading the other buffer, so the next
+    // frame's sort can be queued without waiting for the previous frame.
+    uint32_t* perm[2] = {nullptr, nullptr};
+    uint32_t perm_cur = 0;             // perm[perm_cur] holds the latest permutation
     uint32_t sort_passes = 0;
     uint32_t sort_slots = 1024, pair_slots = 1024;   // resident workgroups of the scatter kernels (CUs x blocks/CU)
     float cam[3] = {0, 0, 0};
@@ -236,4 +250,5 @@ int gsx_launch_select_octree(gsx_ctx* c, const float vp[16], float thr);
 int gsx_launch_select_hc(gsx_ctx* c, const float cam[3], float thr);
 int gsx_launch_sort_list(gsx_ctx* c, uint32_t m); // ascending re-order of an explicit index list
 int gsx_launch_render(gsx_ctx* c, const gsx_uniforms* u, uint32_t w, uint32_t h, uint32_t y0, uint32_t y1);
+void gsx_sample_drain(gsx_ctx* c, uint32_t slot);   // folds a finished level-2 sample into samp_sum_ms / samp_n
 int gsx_frame_finish(gsx_ctx* c);                // waits for the queued frame; runs extra iterations if ranks are left

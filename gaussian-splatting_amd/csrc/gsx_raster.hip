@@ -724,7 +724,7 @@ static int ensure_pairs(gsx_ctx* c, uint64_t budget) {
 static int launch_iteration(gsx_ctx* c, uint32_t iter, uint32_t window, bool first) {
     const GsxFrameState& f = c->frame;
     const GsxViewParams& vp = *reinterpret_cast<const GsxViewParams*>(f.vp_blob);
-    const uint32_t* sorted = c->vals[c->sorted_buf];
+    const uint32_t* sorted = f.sorted;
     const uint32_t nb = gsx_div_up(window, GSX_BIN_TILE);
     const uint32_t budget = static_cast<uint32_t>(c->pair_cap);
     if (nb > 0) {
@@ -838,6 +838,7 @@ int gsx_launch_render(gsx_ctx* c, const gsx_uniforms* u, uint32_t w, uint32_t h,
     GsxFrameState& f = c->frame;
     std::memcpy(f.vp_blob, &vp, sizeof(vp));
     f.mode = mode;
+    f.sorted = c->perm[c->perm_cur];
     f.n_tiles = n_tiles;
     f.continuing = false;
 

@@ -187,21 +187,21 @@ static void key_bounds(const gsx_ctx* c, uint32_t* key_lo, uint32_t* key_span) {
 template <typename KeyT, int NT, int IPT>
 static void launch_pass(gsx_ctx* c, hipStream_t st, uint32_t g, const KeyT* kin, const uint32_t* vin, KeyT* kout, uint32_t* vout,
                         const uint32_t* count_ptr, uint32_t shift, uint32_t bits, uint32_t* ws, uint32_t cols, bool need_hist,
-                        bool iota, int ev_pass /* -1 = no events */) {
+                        bool iota, hipEvent_t ev0, hipEvent_t ev1 /* null = no events */) {
     constexpr uint32_t TILE = NT * IPT;
     uint32_t* cnt = ws;
     uint32_t* totals = ws + static_cast<uint64_t>(GSX_RADIX_MAX_DIGITS) * cols;
     if (need_hist)
         hipLaunchKernelGGL((k_radix_hist<KeyT, NT>), dim3(g), dim3(NT), 0, st, kin, count_ptr, shift, bits, cnt, TILE, cols);
     hipLaunchKernelGGL((k_radix_scan<0>), dim3(1u << bits), dim3(256), 0, st, cnt, count_ptr, TILE, cols, totals);
-    if (ev_pass >= 0) (void)hipEventRecord(c->ev[EV_X0 + 2 * ev_pass], st);
+    if (ev0) (void)hipEventRecord(ev0, st);
     if (iota)
         hipLaunchKernelGGL((k_radix_scatter<KeyT, NT, IPT, true>), dim3(g), dim3(NT), 0, st, kin, vin, kout, vout, count_ptr, shift,
                            bits, cnt, totals, cols);
     else
         hipLaunchKernelGGL((k_radix_scatter<KeyT, NT, IPT, false>), dim3(g), dim3(NT), 0, st, kin, vin, kout, vout, count_ptr, shift,
                            bits, cnt, totals, cols);
-    if (ev_pass >= 0) (void)hipEventRecord(c->ev[EV_X0 + 2 * ev_pass + 1], st);
+    if (ev1) (void)hipEventRecord(ev1, st);
 }
 
 int gsx_launch_sort(gsx_ctx* c) {
@@ -225,18 +225,28 @@ int gsx_launch_sort(gsx_ctx* c) {
     uint32_t cur = 0;
     c->sampled_pass = (c->prof_level == 2 && plan.n_passes > 0) ? static_cast<int>(c->prof_frame % static_cast<uint32_t>(plan.n_passes)) : -1;
     ++c->prof_frame;
+    hipEvent_t samp0 = nullptr, samp1 = nullptr;
+    if (c->sampled_pass >= 0) {
+        const uint32_t slot = c->samp_pos++ % GSX_SAMPLE_RING;
+        gsx_sample_drain(c, slot);                  // (a slot comes round again 32 frames later: long finished)
+        c->samp_pass[slot] = c->sampled_pass;
+        samp0 = c->samp_ev[slot][0];
+        samp1 = c->samp_ev[slot][1];
+    }
+    uint32_t* result = c->perm[c->perm_cur ^ 1u];
     for (int p = 0; p < plan.n_passes; ++p) {
-        const bool first = p == 0;
+        const bool first = p == 0, last = p + 1 == plan.n_passes;
+        hipEvent_t e0 = c->profiling ? c->ev[EV_X0 + 2 * p] : (c->sampled_pass == p ? samp0 : nullptr);
+        hipEvent_t e1 = c->profiling ? c->ev[EV_X0 + 2 * p + 1] : (c->sampled_pass == p ? samp1 : nullptr);
         launch_pass<uint32_t, GSX_SORT_NT, GSX_SORT_IPT>(c, c->stream, g, c->keys[cur], first ? c->sel_idx : c->vals[cur], c->keys[cur ^ 1],
-                                                          c->vals[cur ^ 1], c->m_dev, plan.shift[p], plan.bits[p], c->sort_ws, cols,
-                                                          /*need_hist=*/!first, /*iota=*/first && c->sel_iota,
-                                                          (c->profiling || c->sampled_pass == p) ? p : -1);
+                                                          last ? result : c->vals[cur ^ 1], c->m_dev, plan.shift[p], plan.bits[p], c->sort_ws,
+                                                          cols, /*need_hist=*/!first, /*iota=*/first && c->sel_iota, e0, e1);
         cur ^= 1;
     }
+    c->perm_cur ^= 1u;
     if (c->profiling) GSX_HIP(c, hipEventRecord(c->ev[EV_SORT1], c->stream));
     GSX_HIP(c, hipGetLastError());
     c->sorted_valid = true;
-    c->sorted_buf = cur;
     c->sort_passes = static_cast<uint32_t>(plan.n_passes);
     return GSX_OK;
 }
@@ -260,4 +270,17 @@ uint32_t gsx_sort_slots(int cus) {
     int per = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, k_radix_scatter<uint32_t, GSX_SORT_NT, GSX_SORT_IPT, false>, GSX_SORT_NT, 0) != hipSuccess || per < 1) per = 2;
     return static_cast<uint32_t>(cus) * static_cast<uint32_t>(per);
+}
+
+// Level-2 profiling: folds the sample in ring slot `slot` into the per-pass sums (waits for its stop event if needed).
+void gsx_sample_drain(gsx_ctx* c, uint32_t slot) {
+    const int p = c->samp_pass[slot];
+    if (p < 0) return;
+    c->samp_pass[slot] = -1;
+    float ms = 0.0f;
+    if (hipEventSynchronize(c->samp_ev[slot][1]) != hipSuccess) return;
+    if (hipEventElapsedTime(&ms, c->samp_ev[slot][0], c->samp_ev[slot][1]) != hipSuccess) return;
+    if (p < 4) { c->samp_sum_ms[p] += ms; ++c->samp_n[p]; }
+    c->samp_last_ms = ms;
+    c->samp_last_pass = p;
 }

@@ -99,9 +99,15 @@ int gsx_sync(gsx_ctx* ctx);
 /* 0 = no events (default).  1 = HIP events around every stage and every radix scatter launch
  * (gsx_get_timings fills all *_ms fields; the ~20 events cost tens of microseconds per frame).
  * 2 = sampled: per frame only ONE k_radix_scatter launch of the depth sort is bracketed, the pass
- * rotating frame by frame (scatter_ms = that launch, scatter_sample says which pass). */
+ * rotating frame by frame (scatter_ms = the latest such launch, scatter_sample says which pass).
+ * The samples go through a ring of event pairs, so frames can be queued back to back without
+ * reading anything in between; gsx_get_scatter_samples returns what has accumulated. */
 int gsx_set_profiling(gsx_ctx* ctx, int enabled);
 int gsx_get_timings(gsx_ctx* ctx, gsx_timings* out);
+/* Profiling level 2 (no counterpart in the reference): per radix pass p < 4 of the depth sort, the summed
+ * duration (ms) and the number of sampled k_radix_scatter launches since the last reset.  Waits for the
+ * queued work like gsx_get_timings; reset != 0 clears the sums. */
+int gsx_get_scatter_samples(gsx_ctx* ctx, double sum_ms[4], uint32_t launches[4], int reset);
 /* Tuning knobs of the frame loop (no counterpart in the reference; 0 restores the default):
  *   "pair_budget"   (tile, splat) pairs one near -> far iteration may emit (sizes the pair buffers,
  *                   12 bytes per pair); the device cuts iterations to fit and a frame that needs

@@ -303,3 +303,54 @@ def test_20m_scene_properties(gsx_fresh, pkg, oracle, synth):
         assert np.all(img[..., 3] == 255) and img[..., :3].std() > 10
         assert np.array_equal(gsx.render(u, w, h), img) or np.abs(gsx.render(u, w, h).astype(np.int32) - img.astype(np.int32)).max() <= 1
     del splats
+
+
+def _read_device(ptr, nbytes):
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    out = np.empty(nbytes, np.uint8)
+    rc = hip.hipMemcpy(C.c_void_p(out.ctypes.data), C.c_void_p(ptr), C.c_size_t(nbytes), C.c_int(2))   # device -> host
+    assert rc == 0
+    return out
+
+
+def test_frames_queued_back_to_back(gsx_fresh, pkg, oracle, synth):
+    # a viewer queues frame k+1's sort while frame k is still running: the sort writes the other permutation buffer, and
+    # continuation iterations of frame k (forced here by a small pair budget) are queued AFTER that sort and must still
+    # draw frame k's permutation
+    gsx = gsx_fresh
+    w, h = 240, 176
+    splats = dense_scene(oracle, synth, 20000, seed=5)
+    for k, v in {"chunk_first": 512, "chunk_growth": 2, "pair_budget": 20000, "no_history": 1}.items():
+        gsx.set_option(k, v)
+    gsx.upload(splats)
+    cams = [camera(oracle, w, h, steps=s) for s in (0, 3, 6)]
+    unis = [pkg.make_uniforms(proj, view) for view, proj, _ in cams]
+    ref, perms = [], []
+    for (view, proj, cam), u in zip(cams, unis):          # one frame at a time, each read back before the next
+        perms.append(gsx.sort(cam))
+        ref.append(gsx.render(u, w, h).copy())
+    check_image(ref[1], oracle.render(splats, perms[1], orc.make_uniforms(cams[1][1], cams[1][0]), w, h))
+    assert not np.array_equal(ref[0], ref[1])
+    gsx.set_profiling(2)
+    gsx.scatter_samples(reset=True)
+    gsx.sort(cams[0][2], download=False)
+    for k in range(3):
+        gsx.render(unis[k], w, h, download=False)
+        if k + 1 < 3:
+            gsx.sort(cams[k + 1][2], download=False)       # queued behind frame k without waiting for it
+        gsx.sync()                                         # finishes frame k (its extra iterations run after that sort)
+        assert gsx.timings()["render_iters"] > 4
+        ptr, fw, fh = gsx.framebuffer_dev()
+        assert (fw, fh) == (w, h)
+        img = _read_device(ptr, w * h * 4).reshape(h, w, 4)
+        assert np.array_equal(img, ref[k]), f"frame {k} changed when the next sort was queued early"
+    # two sorts in a row without a frame between them, then a frame of the later one
+    gsx.sort(cams[0][2], download=False)
+    gsx.sort(cams[1][2], download=False)
+    assert np.array_equal(gsx.render(unis[1], w, h), ref[1])
+    assert np.array_equal(gsx.sort(cams[2][2]), perms[2])
+    means, launches = gsx.scatter_samples()
+    assert sum(launches.values()) == 6 and all(v > 0.0 for v in means.values())
+    passes = gsx.timings()["sort_passes"]
+    assert sorted(launches) == list(range(min(passes, 6)))   # the sampled pass rotates frame by frame
