@@ -95,12 +95,15 @@ int gsx_create(int device, gsx_ctx** out) {
         c->samp_pass[i] = -1;
         if (hipEventCreate(&c->samp_ev[i][0]) != hipSuccess || hipEventCreate(&c->samp_ev[i][1]) != hipSuccess) return fail(GSX_E_HIP);
     }
-    if (hipMalloc(reinterpret_cast<void**>(&c->ctl), sizeof(GsxFrameCtl)) != hipSuccess) return fail(GSX_E_NOMEM);
-    if (hipMalloc(reinterpret_cast<void**>(&c->aux), 128) != hipSuccess) return fail(GSX_E_NOMEM);
-    if (hipHostMalloc(reinterpret_cast<void**>(&c->aux_host), 128, hipHostMallocDefault) != hipSuccess) return fail(GSX_E_NOMEM);
+    // control block and aux words: one allocation (aux GSX_AUX_OFFSET bytes in, on cache lines of its own) so that the
+    // frame's end needs a single device -> host copy
+    static_assert(sizeof(GsxFrameCtl) <= GSX_AUX_OFFSET, "aux words must not share the control block's lines");
+    if (hipMalloc(reinterpret_cast<void**>(&c->ctl), GSX_AUX_OFFSET + 256) != hipSuccess) return fail(GSX_E_NOMEM);
+    c->aux = reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(c->ctl) + GSX_AUX_OFFSET);
     if (hipMalloc(reinterpret_cast<void**>(&c->live_bits), GSX_MAX_TILES_Y * GSX_LIVE_ROW_WORDS * 4) != hipSuccess) return fail(GSX_E_NOMEM);
-    if (hipHostMalloc(reinterpret_cast<void**>(&c->ctl_host), sizeof(GsxFrameCtl), hipHostMallocDefault) != hipSuccess)
+    if (hipHostMalloc(reinterpret_cast<void**>(&c->ctl_host), GSX_AUX_OFFSET + 128, hipHostMallocDefault) != hipSuccess)
         return fail(GSX_E_NOMEM);
+    c->aux_host = reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(c->ctl_host) + GSX_AUX_OFFSET);
     if (hipMalloc(reinterpret_cast<void**>(&c->m_dev), 16) != hipSuccess) return fail(GSX_E_NOMEM);
     if (hipMalloc(reinterpret_cast<void**>(&c->pair_total_dev), 16) != hipSuccess) return fail(GSX_E_NOMEM);
     if (hipMalloc(reinterpret_cast<void**>(&c->aabb_dev), 32) != hipSuccess) return fail(GSX_E_NOMEM);
@@ -127,11 +130,9 @@ int gsx_destroy(gsx_ctx* c) {
     for (int b = 0; b < 2; ++b) { dev_free(&c->keys[b]); dev_free(&c->vals[b]); dev_free(&c->perm[b]); dev_free(&c->pair_key[b]); dev_free(&c->pair_val[b]); }
     dev_free(&c->sort_ws); dev_free(&c->aabb_dev); dev_free(&c->flags); dev_free(&c->pair_ws);
     dev_free(&c->splat_ntiles); dev_free(&c->scan_block_sums);
-    dev_free(&c->tile_start); dev_free(&c->pair_total_dev); dev_free(&c->fb);
+    dev_free(&c->pair_total_dev); dev_free(&c->fb);
     dev_free(&c->sub_off); dev_free(&c->rank_box); dev_free(&c->rank_rec); dev_free(&c->ctl); dev_free(&c->live_bits); dev_free(&c->tile_state); dev_free(&c->accum);
     if (c->ctl_host) (void)hipHostFree(c->ctl_host);
-    if (c->aux_host) (void)hipHostFree(c->aux_host);
-    dev_free(&c->aux);
     if (c->frame_ev) (void)hipEventDestroy(c->frame_ev);
     for (int i = 0; i < GSX_SAMPLE_RING; ++i)
         for (int k = 0; k < 2; ++k)
@@ -479,7 +480,6 @@ int gsx_render(gsx_ctx* c, const gsx_uniforms* u, uint32_t width, uint32_t heigh
 int gsx_debug_read(gsx_ctx* c, int what, void* out, uint64_t bytes) {
     const void* src = nullptr;
     switch (what) {
-        case 1: src = c->tile_start; break;
         case 2: src = c->pair_val[0]; break;
         case 3: src = c->pair_key[0]; break;
         case 4: src = c->pair_val[1]; break;

@@ -10,6 +10,7 @@
 
 #define GSX_WAVE 64
 #define GSX_SAMPLE_RING 32
+#define GSX_AUX_OFFSET 512   // bytes from the frame control block to the aux words (same allocation)
 
 // ---- sort geometry: one workgroup sorts one tile of NT*IPT keys per pass ----
 #ifndef GSX_SORT_NT
@@ -158,8 +159,6 @@ struct gsx_ctx {
     uint16_t* pair_key[2] = {nullptr, nullptr};
     uint32_t* pair_val[2] = {nullptr, nullptr};
     uint64_t pair_cap = 0;
-    uint32_t* tile_start = nullptr;    // n_tiles + 1
-    uint64_t tile_cap = 0;
     uint32_t* pair_total_dev = nullptr;
     uint8_t* fb = nullptr;             // RGBA8 width*height
     uint64_t fb_cap = 0;
@@ -176,7 +175,7 @@ struct gsx_ctx {
     GsxFrameCtl* ctl = nullptr;
     GsxFrameCtl* ctl_host = nullptr;   // pinned copy read after the frame
     // aux[0] = cursor of the running iteration (plain data), aux[16] = ranks from the near end consumed by the tiles
-    // retired so far (atomicMax).  Kept OFF the control block's cache line: that line is hammered by returnless
+    // retired so far (atomicMax), aux[32] = pair count of the running iteration (second 128-byte line: never an atomic).  Kept OFF the control block's cache line: that line is hammered by returnless
     // atomics while tiles retire, and any load from it then queues behind them (measured: raster 3x slower).
     uint32_t* aux = nullptr;
     uint32_t* aux_host = nullptr;      // pinned, 32 words

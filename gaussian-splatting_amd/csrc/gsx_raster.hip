@@ -158,7 +158,7 @@ __global__ __launch_bounds__(256) void k_frame_init(GsxFrameCtl* __restrict__ ct
                                                     uint32_t tiles_x, uint32_t tiles_y, uint32_t* __restrict__ aux) {
     const uint32_t lw = (tiles_x + 31u) / 32u, n_tiles = tiles_x * tiles_y;
     const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x, gsz = gridDim.x * blockDim.x;
-    if (gtid < 32) aux[gtid] = 0u;
+    if (gtid < 64) aux[gtid] = 0u;
     if (gtid < sizeof(GsxFrameCtl) / 4) {
         uint32_t v = 0;
         if (gtid == offsetof(GsxFrameCtl, m) / 4) v = *m_ptr;
@@ -434,6 +434,7 @@ __global__ __launch_bounds__(1024) void k_chunk_scan(GsxFrameCtl* __restrict__ c
         ctl->pairs = s_pairs;
         aux[0] = cur;                                   // for k_raster, off the control block's line
         aux[1] = m;
+        aux[32] = s_pairs;                              // the iteration's pair count, on a line of its own (k_raster)
         if (iter == 0u && cur == 0u) { aux[2] = s_pairs; aux[3] = take; }   // density of the nearest window, for the host's schedule
         ctl->cursor[iter + 1] = cur + take;
         const uint32_t tp = ctl->total_pairs;
@@ -447,17 +448,21 @@ __global__ __launch_bounds__(1024) void k_chunk_scan(GsxFrameCtl* __restrict__ c
 
 // K4c (stable radix sort of the pairs by 16-bit tile id) uses gsx_radix.hpp.
 
-// tile_start[t] = lower_bound(sorted pair keys, t), t in [0, n_tiles]
-__global__ __launch_bounds__(256) void k_tile_ranges(const uint16_t* __restrict__ keys, const uint32_t* __restrict__ count_ptr,
-                                                     uint32_t n_tiles, uint32_t* __restrict__ tile_start) {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t > n_tiles) return;
-    uint32_t lo = 0, hi = *count_ptr;
-    while (lo < hi) {
-        const uint32_t mid = lo + ((hi - lo) >> 1);
-        if (keys[mid] < t) lo = mid + 1; else hi = mid;
+// lower_bound(sorted pair keys, target) by one wave: 64-ary search, one probe per lane and round (four dependent
+// loads for 8 M pairs).  Every lane returns the result.
+__device__ __forceinline__ uint32_t gsx_wave_lower_bound(const uint16_t* __restrict__ keys, uint32_t n, uint32_t target, uint32_t lane) {
+    uint32_t lo = 0, len = n;                           // the answer lies in [lo, lo + len]
+    while (len > 0u) {
+        const uint32_t end = lo + len;
+        const uint32_t step = (len + 63u) / 64u;
+        const uint32_t idx = lo + (lane + 1u) * step - 1u;                    // last key of this lane's segment
+        const bool lt = idx < end && static_cast<uint32_t>(keys[idx]) < target;
+        const uint32_t cnt = static_cast<uint32_t>(__popcll(__builtin_amdgcn_ballot_w64(lt)));   // leading segments entirely below
+        lo += cnt * step;
+        if (lo >= end) return end;
+        len = min(step - 1u, end - lo);                 // (the segment's last key is >= target, or the segment is cut by `end`)
     }
-    tile_start[t] = lo;
+    return lo;
 }
 
 // ---------------------------------------------------------------------------
@@ -513,7 +518,7 @@ __device__ __forceinline__ uint32_t gsx_pack_rgba8(float r, float g, float b) {
 // horizontally adjacent pixels (2*(lane&7), 2*(lane&7)+1) of row lane>>3, so that every arithmetic step of the
 // shading loop is one packed-f32 instruction for both pixels (measured: the loop is VALU-bound).
 template <int MODE /*0 blend, 1 threshold (bayerSize 10), 2 bayer dither*/>
-__global__ __launch_bounds__(GSX_RASTER_NT) void k_raster(const uint32_t* __restrict__ tile_start, const uint32_t* __restrict__ pair_val,
+__global__ __launch_bounds__(GSX_RASTER_NT) void k_raster(const uint16_t* __restrict__ pair_key, const uint32_t* __restrict__ pair_val,
                                                           const float4* __restrict__ rank_rec, uint32_t iter, GsxViewParams vp, uint32_t first,
                                                           uint32_t* __restrict__ tile_state, uint32_t* __restrict__ live_bits,
                                                           float4* __restrict__ accum, GsxFrameCtl* __restrict__ ctl,
@@ -526,14 +531,22 @@ __global__ __launch_bounds__(GSX_RASTER_NT) void k_raster(const uint32_t* __rest
     __shared__ uint32_t s_rank[MODE == 2 ? GSX_RASTER_BATCH : 1];
     __shared__ uint64_t s_mask[NW][NW];        // [half][staging wave]: splats of the batch whose quad touches the half
     __shared__ int s_live[2];
+    __shared__ uint32_t s_range[2];
     const uint32_t tile = blockIdx.x;
     const uint32_t state = tile_state[tile];           // 0 untouched, 1 accumulators valid, 2 retired
     if (state == 2u) return;
-    const uint32_t begin = tile_start[tile], end = tile_start[tile + 1];
+    const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    // this tile's slice of the iteration's sorted pair list: wave 0 finds its begin, wave 1 its end (the pair count comes
+    // from the aux words, on a cache line no atomic touches)
+    {
+        const uint32_t at = gsx_wave_lower_bound(pair_key, aux[32], tile + wave, lane);
+        if (lane == 0) s_range[wave] = at;
+    }
+    __syncthreads();
+    const uint32_t begin = s_range[0], end = s_range[1];
     if (begin == end && !first) return;                // nothing new for this tile in this iteration
     const uint32_t ttx = tile % vp.tiles_x, tty = tile / vp.tiles_x;
     const uint32_t tx = ttx, ty = tty + vp.tile_y0;
-    const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const uint32_t px = tx * GSX_TILE_W + (lane & 7) * 2, py = ty * GSX_TILE_H + wave * 8 + (lane >> 3);
     const gsx_f2 fx = {static_cast<float>(px) + 0.5f, static_cast<float>(px) + 1.5f};
     const float fy = static_cast<float>(py) + 0.5f;
@@ -760,18 +773,16 @@ static int launch_iteration(gsx_ctx* c, uint32_t iter, uint32_t window, bool fir
                            plan.bits[p], cnt, totals, cols);
         cur ^= 1;
     }
-    hipLaunchKernelGGL(k_tile_ranges, dim3(gsx_div_up(f.n_tiles + 1, 256)), dim3(256), 0, c->stream, c->pair_key[cur], count_ptr,
-                       f.n_tiles, c->tile_start);
     if (c->profiling && iter < GSX_MAX_SCHED && !f.continuing) GSX_HIP(c, hipEventRecord(c->ev[EV_IT0 + 2 * iter], c->stream));
     const uint32_t fi = first ? 1u : 0u;
     if (f.mode == 0)
-        hipLaunchKernelGGL(k_raster<0>, dim3(f.n_tiles), dim3(GSX_RASTER_NT), 0, c->stream, c->tile_start, c->pair_val[cur], c->rank_rec, iter, vp,
+        hipLaunchKernelGGL(k_raster<0>, dim3(f.n_tiles), dim3(GSX_RASTER_NT), 0, c->stream, c->pair_key[cur], c->pair_val[cur], c->rank_rec, iter, vp,
                            fi, c->tile_state, c->live_bits, c->accum, c->ctl, c->aux, c->fb);
     else if (f.mode == 1)
-        hipLaunchKernelGGL(k_raster<1>, dim3(f.n_tiles), dim3(GSX_RASTER_NT), 0, c->stream, c->tile_start, c->pair_val[cur], c->rank_rec, iter, vp,
+        hipLaunchKernelGGL(k_raster<1>, dim3(f.n_tiles), dim3(GSX_RASTER_NT), 0, c->stream, c->pair_key[cur], c->pair_val[cur], c->rank_rec, iter, vp,
                            fi, c->tile_state, c->live_bits, c->accum, c->ctl, c->aux, c->fb);
     else
-        hipLaunchKernelGGL(k_raster<2>, dim3(f.n_tiles), dim3(GSX_RASTER_NT), 0, c->stream, c->tile_start, c->pair_val[cur], c->rank_rec, iter, vp,
+        hipLaunchKernelGGL(k_raster<2>, dim3(f.n_tiles), dim3(GSX_RASTER_NT), 0, c->stream, c->pair_key[cur], c->pair_val[cur], c->rank_rec, iter, vp,
                            fi, c->tile_state, c->live_bits, c->accum, c->ctl, c->aux, c->fb);
     if (c->profiling && iter < GSX_MAX_SCHED && !f.continuing) GSX_HIP(c, hipEventRecord(c->ev[EV_IT0 + 2 * iter + 1], c->stream));
     return GSX_OK;
@@ -815,7 +826,6 @@ int gsx_launch_render(gsx_ctx* c, const gsx_uniforms* u, uint32_t w, uint32_t h,
         GSX_HIP(c, hipMemsetAsync(c->fb, 0, static_cast<uint64_t>(w) * h * 4, c->stream));
         c->fb_w = w; c->fb_h = h;
     }
-    if ((rc = ensure(c, &c->tile_start, &c->tile_cap, static_cast<uint64_t>(n_tiles) + 2)) != GSX_OK) return rc;
     if ((rc = ensure(c, &c->tile_state, &c->tile_state_cap, static_cast<uint64_t>(n_tiles) + 2)) != GSX_OK) return rc;
     if ((rc = ensure(c, &c->accum, &c->accum_cap, static_cast<uint64_t>(n_tiles) * GSX_TILE_W * GSX_TILE_H)) != GSX_OK) return rc;
     {
@@ -884,8 +894,7 @@ int gsx_launch_render(gsx_ctx* c, const gsx_uniforms* u, uint32_t w, uint32_t h,
         ++n_iters;
     } while (covered < need);
     f.n_iters = n_iters;
-    GSX_HIP(c, hipMemcpyAsync(c->ctl_host, c->ctl, sizeof(GsxFrameCtl), hipMemcpyDeviceToHost, c->stream));
-    GSX_HIP(c, hipMemcpyAsync(c->aux_host, c->aux, 128, hipMemcpyDeviceToHost, c->stream));
+    GSX_HIP(c, hipMemcpyAsync(c->ctl_host, c->ctl, GSX_AUX_OFFSET + 128, hipMemcpyDeviceToHost, c->stream));   // control block + aux
     GSX_HIP(c, hipEventRecord(c->frame_ev, c->stream));
     c->frame_pending = true;
     if (c->profiling) GSX_HIP(c, hipEventRecord(c->ev[EV_RAST1], c->stream));
@@ -926,8 +935,7 @@ int gsx_frame_finish(gsx_ctx* c) {
         GSX_HIP(c, hipMemcpyAsync(&c->ctl->cursor[0], &c->ctl->cursor[last], 4, hipMemcpyDeviceToDevice, c->stream));
         GSX_HIP(c, hipMemcpyAsync(&c->ctl->stall, &zero, 4, hipMemcpyHostToDevice, c->stream));
         if ((rc = launch_iteration(c, 0, h.m - cur, false)) != GSX_OK) { c->frame_pending = false; return rc; }
-        GSX_HIP(c, hipMemcpyAsync(c->ctl_host, c->ctl, sizeof(GsxFrameCtl), hipMemcpyDeviceToHost, c->stream));
-        GSX_HIP(c, hipMemcpyAsync(c->aux_host, c->aux, 128, hipMemcpyDeviceToHost, c->stream));
+        GSX_HIP(c, hipMemcpyAsync(c->ctl_host, c->ctl, GSX_AUX_OFFSET + 128, hipMemcpyDeviceToHost, c->stream));
         GSX_HIP(c, hipStreamSynchronize(c->stream));
         last = 1;
     }

@@ -149,7 +149,10 @@ int gsx_get_selection(gsx_ctx* ctx, uint32_t* idx_out_host, uint32_t capacity, u
  * glm::distance(position, cameraPos), order = distance descending, ties by
  * ascending index.  Sorts the current selection; the permutation stays in HBM
  * (replaces the queue.writeBuffer(sortIndexBuffer) upload, SplatMesh.h:56-57).
- * idx_out_host (nullable) receives the m sorted indices. ---- */
+ * idx_out_host (nullable) receives the m sorted indices.
+ * With idx_out_host == NULL the call only queues the sort; it may be issued while
+ * a frame queued by gsx_render is still running (the result goes to a second
+ * permutation buffer, so that frame keeps drawing its own order). ---- */
 int gsx_sort(gsx_ctx* ctx, const float cam_pos[3], uint32_t* idx_out_host);
 int gsx_get_sorted_dev(gsx_ctx* ctx, const uint32_t** idx_dev, uint32_t* m);
 /* Parity aid: the f32 distance key (SplatMesh.h:93) of every selected splat, in
