@@ -36,8 +36,6 @@ int check_flags(gsx_ctx* c) {
     if (frc) return frc;
     GSX_HIP(c, hipMemcpyAsync(c->flags_host, c->flags, sizeof(GsxDevFlags), hipMemcpyDeviceToHost, c->stream));
     GSX_HIP(c, hipStreamSynchronize(c->stream));
-    if (c->flags_host->spin_expired) { c->err = "device: bounded look-back spin expired (results invalid)"; return GSX_E_INTERNAL; }
-    if (c->flags_host->pair_overflow) { c->err = "device: tile pair buffer overflow"; return GSX_E_INTERNAL; }
     if (c->flags_host->bad_index) { c->err = "selection list holds an id >= n"; return GSX_E_INVALID; }
     if (c->flags_host->key_bound) { c->err = "device: a depth key left the scene's distance bound (non-finite position?)"; return GSX_E_INTERNAL; }
     return GSX_OK;
@@ -105,7 +103,6 @@ int gsx_create(int device, gsx_ctx** out) {
         return fail(GSX_E_NOMEM);
     c->aux_host = reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(c->ctl_host) + GSX_AUX_OFFSET);
     if (hipMalloc(reinterpret_cast<void**>(&c->m_dev), 16) != hipSuccess) return fail(GSX_E_NOMEM);
-    if (hipMalloc(reinterpret_cast<void**>(&c->pair_total_dev), 16) != hipSuccess) return fail(GSX_E_NOMEM);
     if (hipMalloc(reinterpret_cast<void**>(&c->aabb_dev), 32) != hipSuccess) return fail(GSX_E_NOMEM);
     if (hipMalloc(reinterpret_cast<void**>(&c->flags), sizeof(GsxDevFlags)) != hipSuccess) return fail(GSX_E_NOMEM);
     if (hipHostMalloc(reinterpret_cast<void**>(&c->host_word), 64, hipHostMallocDefault) != hipSuccess)
@@ -129,8 +126,8 @@ int gsx_destroy(gsx_ctx* c) {
     dev_free(&c->lod_stop); dev_free(&c->lod_emit); dev_free(&c->lod_block_sums);
     for (int b = 0; b < 2; ++b) { dev_free(&c->keys[b]); dev_free(&c->vals[b]); dev_free(&c->perm[b]); dev_free(&c->pair_key[b]); dev_free(&c->pair_val[b]); }
     dev_free(&c->sort_ws); dev_free(&c->aabb_dev); dev_free(&c->flags); dev_free(&c->pair_ws);
-    dev_free(&c->splat_ntiles); dev_free(&c->scan_block_sums);
-    dev_free(&c->pair_total_dev); dev_free(&c->fb);
+    dev_free(&c->scan_block_sums);
+    dev_free(&c->fb);
     dev_free(&c->sub_off); dev_free(&c->rank_box); dev_free(&c->rank_rec); dev_free(&c->ctl); dev_free(&c->live_bits); dev_free(&c->tile_state); dev_free(&c->accum);
     if (c->ctl_host) (void)hipHostFree(c->ctl_host);
     if (c->frame_ev) (void)hipEventDestroy(c->frame_ev);

@@ -64,9 +64,9 @@ struct GsxFrameState {
 
 // Error/diagnostic words written by kernels (never zeroed implicitly).
 struct GsxDevFlags {
-    uint32_t spin_expired;   // a bounded look-back spin ran out
+    uint32_t reserved0;
     uint32_t asym_cov;       // upload saw a non-symmetric covariance block
-    uint32_t pair_overflow;  // binner produced more pairs than the buffer holds
+    uint32_t reserved1;
     uint32_t bad_index;      // a selection list named an id >= n
     uint32_t key_bound;      // a depth key fell outside the host-computed [dmin, dmax] bound (NaN position?)
     uint32_t pad[3];
@@ -153,13 +153,11 @@ struct gsx_ctx {
     GsxDevFlags* flags_host = nullptr; // pinned
 
     // raster
-    uint32_t* splat_ntiles = nullptr;  // per sorted rank: number of tiles touched, then its exclusive scan
     uint32_t* scan_block_sums = nullptr;
     uint64_t rank_cap = 0;
     uint16_t* pair_key[2] = {nullptr, nullptr};
     uint32_t* pair_val[2] = {nullptr, nullptr};
     uint64_t pair_cap = 0;
-    uint32_t* pair_total_dev = nullptr;
     uint8_t* fb = nullptr;             // RGBA8 width*height
     uint64_t fb_cap = 0;
     uint32_t fb_w = 0, fb_h = 0;
@@ -244,7 +242,6 @@ static inline uint32_t gsx_div_up(uint64_t a, uint64_t b) { return static_cast<u
 int gsx_launch_upload(gsx_ctx* c, const void* aos80_dev, uint64_t n);
 int gsx_launch_sort(gsx_ctx* c);                 // keygen + plan + radix passes on the current selection
 int gsx_launch_keys_only(gsx_ctx* c, float* dist_dev);
-int gsx_launch_iota_check(gsx_ctx* c);
 int gsx_launch_select_octree(gsx_ctx* c, const float vp[16], float thr);
 int gsx_launch_select_hc(gsx_ctx* c, const float cam[3], float thr);
 int gsx_launch_sort_list(gsx_ctx* c, uint32_t m); // ascending re-order of an explicit index list

@@ -633,8 +633,9 @@ __global__ __launch_bounds__(GSX_RASTER_NT) void k_raster(const uint16_t* __rest
 #endif
                     if (h0 || h1) {
                         const float4 c = s_c[j];
-                        const gsx_f2 r2 = u * u + v * v;
-                        gsx_f2 alpha = {h0 ? c.w * __expf(-0.5f * r2.x) : 0.0f, h1 ? c.w * __expf(-0.5f * r2.y) : 0.0f};
+                        // exp(-r2/2) = 2^(r2 * -log2(e)/2): one packed multiply for both pixels, then v_exp_f32
+                        const gsx_f2 e2 = (u * u + v * v) * -0.72134752044448170368f;
+                        gsx_f2 alpha = {h0 ? c.w * __builtin_amdgcn_exp2f(e2.x) : 0.0f, h1 ? c.w * __builtin_amdgcn_exp2f(e2.y) : 0.0f};
                         if (MODE == 1) { alpha.x = (alpha.x > vp.bayer_scale) ? 1.0f : 0.0f; alpha.y = (alpha.y > vp.bayer_scale) ? 1.0f : 0.0f; }
                         if (MODE == 2) {
                             const float lim = static_cast<float>(vp.bayer_size * vp.bayer_size + 1u);
