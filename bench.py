@@ -101,6 +101,7 @@ def main():
     ap.add_argument("--scene", default="clustered")
     ap.add_argument("--cpu-frames", type=int, default=20, help="frames of the CPU baseline (0 = skip)")
     ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--opt", action="append", default=[], help="name=value for gsx_set_option (A/B runs; not used by the driver)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -127,6 +128,9 @@ def main():
 
     g = pkg.Gsx(local_rank)
     g.upload(splats)
+    for o in a.opt:
+        k, v = o.split("=")
+        g.set_option(k, int(v))
     g.set_profiling(2)          # sampled: one k_radix_scatter launch per frame carries HIP events
     uniforms = [pkg.make_uniforms(v[1], v[0]) for v in my_views]
 

@@ -216,13 +216,18 @@ __device__ __forceinline__ uint32_t gsx_rank_pairs(const float4 p, const float4 
 // K4a.  Block b of iteration `iter` owns the 1024 ranks hi-1-b*1024 ... hi-(b+1)*1024 (hi = m - cursor),
 // nearest first: pair count of the block -> block_sums[b], and the exclusive in-block pair offset at every
 // 64-rank boundary -> sub_off[b*17 + s] (s = 16 holds the block total).
-__global__ __launch_bounds__(GSX_BIN_NT) void k_chunk_count(const GsxFrameCtl* __restrict__ ctl, uint32_t iter, uint32_t window,
+#ifndef GSX_CNT_NT
+#define GSX_CNT_NT 512           // two ranks per thread: the projection is a long dependent chain behind a 64-B gather, so the
+#endif                           // kernel wants many waves per CU, not many ranks per thread (256 x 4 ranks: +35 us per frame)
+#define GSX_CNT_IPT (GSX_BIN_TILE / GSX_CNT_NT)
+__global__ __launch_bounds__(GSX_CNT_NT) void k_chunk_count(const GsxFrameCtl* __restrict__ ctl, uint32_t iter, uint32_t window,
                                                             const uint32_t* __restrict__ sorted, const GsxGeo* __restrict__ geo,
                                                             const uint32_t* __restrict__ live_bits, GsxViewParams vp,
                                                             uint32_t* __restrict__ block_sums, uint32_t* __restrict__ sub_off,
                                                             uint32_t* __restrict__ rank_box, float4* __restrict__ rank_rec) {
+    static_assert(GSX_CNT_NT * GSX_CNT_IPT == GSX_BIN_TILE && GSX_CNT_NT % (GSX_BIN_SUBS * 1) == 0, "a block owns 1024 ranks");
     const uint32_t tiles_x = vp.tiles_x, tiles_y = vp.tiles_y;
-    __shared__ uint32_t s_tmp[GSX_BIN_NT / 64];
+    __shared__ uint32_t s_tmp[GSX_CNT_NT / 64];
     __shared__ __attribute__((aligned(16))) uint32_t s_live[GSX_MAX_TILES_Y * GSX_LIVE_ROW_WORDS];
     const uint32_t b = blockIdx.x;
     const uint32_t cur = ctl->cursor[iter], m = ctl->m;
@@ -232,43 +237,40 @@ __global__ __launch_bounds__(GSX_BIN_NT) void k_chunk_count(const GsxFrameCtl* _
         if (threadIdx.x <= GSX_BIN_SUBS) sub_off[b * (GSX_BIN_SUBS + 1) + threadIdx.x] = 0u;
         return;
     }
-    const uint32_t lw = (tiles_x + 31u) / 32u;
-    for (uint32_t i = threadIdx.x; i < GSX_LIVE_ROW_WORDS * tiles_y; i += GSX_BIN_NT) {      // rows padded to 8 words
-        const uint32_t ty = i / GSX_LIVE_ROW_WORDS, w = i % GSX_LIVE_ROW_WORDS;
-        s_live[i] = w < lw ? live_bits[ty * lw + w] : 0u;
-    }
-    __syncthreads();
-    uint32_t tot = 0;
-    const uint32_t local0 = b * GSX_BIN_TILE + threadIdx.x * GSX_BIN_IPT;
-    // all gathers of the thread's four ranks are issued before any projection starts (one 64-B line per splat)
-    uint32_t rb[GSX_BIN_IPT];
-    float4 gp[GSX_BIN_IPT], ga[GSX_BIN_IPT], gb[GSX_BIN_IPT], gc[GSX_BIN_IPT];
+    const uint32_t local0 = b * GSX_BIN_TILE + threadIdx.x * GSX_CNT_IPT;
+    // the gathers of the thread's ranks are issued first (one 64-B line per splat), the live-tile mask is staged behind them
+    float4 gp[GSX_CNT_IPT], ga[GSX_CNT_IPT], gb[GSX_CNT_IPT], gc[GSX_CNT_IPT];
     const uint32_t hi = m - cur;
 #pragma unroll
-    for (int j = 0; j < GSX_BIN_IPT; ++j) {
+    for (int j = 0; j < GSX_CNT_IPT; ++j) {
         const uint32_t local = local0 + j;
         const uint32_t idx = sorted[hi - 1u - (local < win ? local : win - 1u)];
         const float4* g = reinterpret_cast<const float4*>(geo + idx);
         gp[j] = g[0]; ga[j] = g[1]; gb[j] = g[2]; gc[j] = g[3];
     }
-    for (int j = 0; j < GSX_BIN_IPT; ++j) {      // (not unrolled: the projection is long)
-        rb[j] = GSX_RBOX_NONE;
+    const uint32_t lw = (tiles_x + 31u) / 32u;
+    for (uint32_t i = threadIdx.x; i < GSX_LIVE_ROW_WORDS * tiles_y; i += GSX_CNT_NT) {      // rows padded to 8 words
+        const uint32_t ty = i / GSX_LIVE_ROW_WORDS, w = i % GSX_LIVE_ROW_WORDS;
+        s_live[i] = w < lw ? live_bits[ty * lw + w] : 0u;
+    }
+    __syncthreads();
+    uint32_t tot = 0;
+    for (int j = 0; j < GSX_CNT_IPT; ++j) {      // (not unrolled: the projection is long)
+        uint32_t rb = GSX_RBOX_NONE;
         float4 a, mm;
         const float4 col = gc[j];
-        const uint32_t cnt = (local0 + j < win) ? gsx_rank_pairs(gp[j], ga[j], gb[j], vp, s_live, rb[j], a, mm) : 0u;
+        const uint32_t cnt = (local0 + j < win) ? gsx_rank_pairs(gp[j], ga[j], gb[j], vp, s_live, rb, a, mm) : 0u;
         if (cnt) {
             // the 48-B screen-space record the rasterizer stages, in window-rank order
             float4* rec = rank_rec + static_cast<uint64_t>(local0 + j) * 3;
             rec[0] = a; rec[1] = mm; rec[2] = col;
         }
+        rank_box[local0 + j] = rb;               // what k_chunk_emit needs per rank, in rank order
         tot += cnt;
     }
-    // what k_chunk_emit needs per rank, in rank order
-    static_assert(GSX_BIN_IPT == 4, "one 16-byte store per thread");
-    reinterpret_cast<uint4*>(rank_box)[local0 / 4] = make_uint4(rb[0], rb[1], rb[2], rb[3]);
     uint32_t block_total;
-    const uint32_t excl = gsx_block_excl_scan<GSX_BIN_NT>(tot, s_tmp, &block_total);
-    constexpr uint32_t TPS = GSX_BIN_NT / GSX_BIN_SUBS;          // threads per 64-rank sub-block
+    const uint32_t excl = gsx_block_excl_scan<GSX_CNT_NT>(tot, s_tmp, &block_total);
+    constexpr uint32_t TPS = GSX_CNT_NT / GSX_BIN_SUBS;          // threads per 64-rank sub-block
     if (threadIdx.x % TPS == 0) sub_off[b * (GSX_BIN_SUBS + 1) + threadIdx.x / TPS] = excl;
     if (threadIdx.x == 0) {
         block_sums[b] = block_total;
@@ -742,7 +744,7 @@ static int launch_iteration(gsx_ctx* c, uint32_t iter, uint32_t window, bool fir
     const uint32_t nb = gsx_div_up(window, GSX_BIN_TILE);
     const uint32_t budget = static_cast<uint32_t>(c->pair_cap);
     if (nb > 0) {
-        hipLaunchKernelGGL(k_chunk_count, dim3(nb), dim3(GSX_BIN_NT), 0, c->stream, c->ctl, iter, window, sorted, c->geo,
+        hipLaunchKernelGGL(k_chunk_count, dim3(nb), dim3(GSX_CNT_NT), 0, c->stream, c->ctl, iter, window, sorted, c->geo,
                            c->live_bits, vp, c->scan_block_sums, c->sub_off, c->rank_box, c->rank_rec);
         hipLaunchKernelGGL(k_chunk_scan, dim3(1), dim3(1024), 0, c->stream, c->ctl, iter, window, nb, c->scan_block_sums, budget, c->aux);
         // slot-parallel: one wave per GSX_EMIT_SLICE pairs.  The pair count is only known on the device (a window of a few
