@@ -10,8 +10,10 @@ data already resident in HBM: depth keys -> stable radix sort -> projection ->
 near-to-far iterations of (occlusion-aware tile binning -> pair sort -> tile raster)
 into a device RGBA8 framebuffer (no readback).
 At N > 1 the path shards by camera view over a replicated splat set (weak
-scaling: every rank renders its own view each step) and the finished frames are
-gathered to rank 0 with RCCL inside the timed region.
+scaling: a step is a batch of N views, rank r renders view r of the pose set) and the finished frames are
+gathered to rank 0 with RCCL inside the timed region: every rank renders into the
+slots of a batch buffer and each full batch of 8 frames goes out in one asynchronous
+gather while the next batch is rendered (multigpu.BatchedFrameGather).
 
 Prints ONE JSON line on rank 0.  `value` = splats sorted (and drawn) per second
 over whole frames, aggregated over ranks; `fps_1080p` and the sort-only rate are
@@ -90,6 +92,11 @@ def cpu_baseline(splats, views, n_frames):
     return splats.shape[0] * n_frames / secs, secs
 
 
+def _dbg(msg):
+    if os.environ.get("GSX_BENCH_DEBUG"):
+        print(f"[bench {time.perf_counter():.3f}] {msg}", file=sys.stderr, flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -101,19 +108,31 @@ def main():
     ap.add_argument("--scene", default="clustered")
     ap.add_argument("--cpu-frames", type=int, default=20, help="frames of the CPU baseline (0 = skip)")
     ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--gather-batch", type=int, default=8, help="frames per RCCL gather at N > 1")
     ap.add_argument("--opt", action="append", default=[], help="name=value for gsx_set_option (A/B runs; not used by the driver)")
     a = ap.parse_args()
+
+    # stdout carries exactly ONE line, the JSON: libraries that print banners to stdout (RCCL prints its version when the
+    # communicator is created) are sent to stderr by swapping the descriptors before anything is loaded
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     import torch
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("GSX_BENCH_FORCE_DIST"):   # (the variable: one-rank rehearsal of the N > 1 code path)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback)"
+    _dbg(f"process group ready: rank {rank}/{world}")
 
     pkg = load_pkg()
     synth = importlib.import_module("gaussian_splatting_amd.synth")
@@ -122,10 +141,11 @@ def main():
     splats = scene.raw_to_splats(pkg, raw, center=False)      # host half of ResourceManager (libgsx, C++)
     W, H = a.width, a.height
     views = orbit_views(pkg, 64, W, H)
-    # view-batch sharding: rank r owns views r, r+world, ... (independent units, no data-path collective)
+    # view-batch sharding (weak scaling): a step of the job is a batch of N views, one per GPU; rank r renders view r of the
+    # pose set at every step, so the per-GPU work is the N = 1 workload whatever N is (independent units, no data-path
+    # collective until the finished frames are gathered)
     mg = importlib.import_module("gaussian_splatting_amd.multigpu")
-    my_views = [views[i] for i in mg.shard_views(len(views), rank, world)] if world > 1 else views[:1]
-
+    my_views = [views[mg.shard_views(len(views), rank, max(world, 1))[0]]]
     g = pkg.Gsx(local_rank)
     g.upload(splats)
     for o in a.opt:
@@ -135,20 +155,32 @@ def main():
     uniforms = [pkg.make_uniforms(v[1], v[0]) for v in my_views]
 
     fb_bytes = W * H * 4
-    gather_buf = None
+    # N > 1: every rank renders straight into the slots of a batch buffer; a full batch (8 frames, SURVEY 8e cfg 4)
+    # goes to rank 0 in one asynchronous RCCL gather while the next batch is rendered (two buffers alternate).
+    bg = None
+    if dist is not None and not a.no_gather:
+        ext = torch.cuda.ExternalStream(g.stream(), device=torch.device("cuda", local_rank))
+        bg = mg.BatchedFrameGather(dist, rank, world, fb_bytes, a.gather_batch, torch.device("cuda", local_rank), stream=ext)
+    frame_no = 0
 
     def step(i):
+        nonlocal frame_no
         v = i % len(my_views)
-        g.sort(my_views[v][2], download=False)
+        g.sort(my_views[v][2], download=False)          # queued behind the running frame
+        if bg is not None:
+            slot = bg.slot(frame_no)
+            g.set_framebuffer_dev(slot.data_ptr(), fb_bytes)   # completes the previous frame into ITS slot first
+            if frame_no:
+                bg.frame_done(frame_no - 1)             # closes a batch every gather_batch frames: async gather
         g.render(uniforms[v], W, H, download=False)
+        frame_no += 1
 
-    def gather():
-        """Framebuffer gather to rank 0 over RCCL (direct sends, one xGMI link per peer)."""
-        nonlocal gather_buf
-        g.sync()
-        ptr, _, _ = g.framebuffer_dev()
-        fb = torch.as_tensor(DevArray(ptr, fb_bytes), device=torch.device("cuda", local_rank))
-        gather_buf = mg.gather_to_rank0(dist, fb, rank, world, gather_buf)
+    def drain():
+        """Complete the last frame and send what is left of the current batch; waits for every gather."""
+        if bg is not None and frame_no:
+            g.set_framebuffer_dev(None)
+            bg.frame_done(frame_no - 1)
+            bg.finish()
 
     def fence():
         if dist is not None:
@@ -156,11 +188,11 @@ def main():
         g.sync()
         torch.cuda.synchronize()
 
+    _dbg("scene uploaded")
     for i in range(a.warmup):
         step(i)
-        if dist is not None and not a.no_gather:
-            gather()
     fence()
+    _dbg("warm-up done")
     g.scatter_samples(reset=True)
     # Frames are queued back to back (the next frame's sort is queued behind the running frame; gsx_render waits for
     # the previous frame only to check whether it needs more iterations).  Nothing is read back inside the loop: the
@@ -168,10 +200,15 @@ def main():
     t0 = time.perf_counter()
     for i in range(a.steps):
         step(i)
-        if dist is not None and not a.no_gather:
-            gather()
+        if i % 16 == 15:
+            _dbg(f"queued step {i}")
+    _dbg("timed steps queued")
+    drain()
+    _dbg("drained")
     fence()
     elapsed = time.perf_counter() - t0
+    _dbg("timed region closed")
+    bg = None                                            # the extra profiling frames below are rank 0's alone: no collective
     per_pass, pass_n = g.scatter_samples(reset=True)     # mean launch duration of each radix pass over the timed region
     t = g.timings()
     pairs = t["tile_pairs"] * a.steps; iters = t["render_iters"] * a.steps; passes = t["sort_passes"] * a.steps
@@ -221,7 +258,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"cfg2: {n}-splat clustered synthetic scene, single view {W}x{H} per step",
                        "splats": n, "width": W, "height": H, "views_per_step_per_gpu": 1,
-                       "sharding": "camera views over replicated splats" + ("" if a.no_gather or world == 1 else " + RCCL framebuffer gather to rank 0")},
+                       "sharding": "camera views over replicated splats" + ("" if a.no_gather or world == 1 else f" + RCCL framebuffer gather to rank 0 in batches of {a.gather_batch} frames")},
             "fps_1080p": K * world / elapsed,
             "sort_only_splats_per_s": n / (keysort_ms * 1e-3),
             "sort_only_ms": keysort_ms,
@@ -244,7 +281,9 @@ def main():
                                    "sample": f"{a.cpu_frames} consecutive frames of the full {n}-splat sortSplats "
                                              f"(distances alloc + key loop + std::sort, {secs:.1f} s of CPU; sort only, the "
                                              "reference has no CPU raster)"}
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    _dbg("closing")
     g.close()
     if dist is not None:
         dist.barrier()

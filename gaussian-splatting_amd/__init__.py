@@ -23,7 +23,7 @@ ABI_SYMBOLS = [
     "gsx_create", "gsx_destroy", "gsx_last_error", "gsx_sync", "gsx_set_profiling", "gsx_get_timings", "gsx_get_scatter_samples", "gsx_set_option",
     "gsx_upload_splats", "gsx_upload_splats_dev", "gsx_select_all", "gsx_select_list", "gsx_set_lod_octree",
     "gsx_set_lod_hc", "gsx_select_octree", "gsx_select_hc", "gsx_get_selection", "gsx_sort", "gsx_get_sorted_dev",
-    "gsx_get_keys", "gsx_render", "gsx_get_framebuffer_dev",
+    "gsx_get_keys", "gsx_render", "gsx_get_framebuffer_dev", "gsx_set_framebuffer_dev", "gsx_get_stream",
     "gsx_host_convert_raw", "gsx_host_load_splat_file", "gsx_host_free", "gsx_host_load_ply_raw", "gsx_host_load_ply_file", "gsx_host_camera", "gsx_host_orbit_pose",
     "gsx_host_octree_build", "gsx_host_hc_build", "gsx_host_gridhc_build", "gsx_host_lod_free", "gsx_host_lod_size",
     "gsx_host_lod_roots", "gsx_host_lod_cells", "gsx_host_lod_splats", "gsx_host_lod_flat_octree", "gsx_host_lod_flat_hc",
@@ -206,6 +206,17 @@ class Gsx:
         w, h = C.c_uint32(0), C.c_uint32(0)
         self._chk(self.lib.gsx_get_framebuffer_dev(self.ctx, C.byref(dev), C.byref(w), C.byref(h)))
         return dev.value, w.value, h.value
+
+    def set_framebuffer_dev(self, dev_ptr, capacity_bytes=0):
+        """Render the following frames into caller-owned device memory (None = the library's own framebuffer);
+        completes the queued frame into the previous target first."""
+        self._chk(self.lib.gsx_set_framebuffer_dev(self.ctx, C.c_void_p(dev_ptr), C.c_uint64(int(capacity_bytes))))
+
+    def stream(self):
+        """hipStream_t (as an integer) every call of this context is queued on, e.g. for torch.cuda.ExternalStream."""
+        st = C.c_void_p()
+        self._chk(self.lib.gsx_get_stream(self.ctx, C.byref(st)))
+        return st.value or 0
 
     # -- misc --
     def sync(self):

@@ -467,7 +467,7 @@ int gsx_render(gsx_ctx* c, const gsx_uniforms* u, uint32_t width, uint32_t heigh
     if (rgba8_out_host) {
         if ((rc = check_flags(c))) return rc;
         const uint64_t row = static_cast<uint64_t>(width) * 4;
-        GSX_HIP(c, hipMemcpy(static_cast<uint8_t*>(rgba8_out_host) + y0 * row, c->fb + y0 * row, (y1 - y0) * row,
+        GSX_HIP(c, hipMemcpy(static_cast<uint8_t*>(rgba8_out_host) + y0 * row, c->fb_cur + y0 * row, (y1 - y0) * row,
                              hipMemcpyDeviceToHost));
     }
     return GSX_OK;
@@ -502,10 +502,26 @@ int gsx_debug_flags(gsx_ctx* c, uint32_t out[8]) {
 
 int gsx_get_framebuffer_dev(gsx_ctx* c, const void** rgba8_dev, uint32_t* width, uint32_t* height) {
     if (!c || !rgba8_dev) return GSX_E_INVALID;
-    if (!c->fb) { c->err = "no frame rendered yet"; return GSX_E_STATE; }
-    *rgba8_dev = c->fb;
+    if (!c->fb_cur) { c->err = "no frame rendered yet"; return GSX_E_STATE; }
+    *rgba8_dev = c->fb_cur;
     if (width) *width = c->fb_w;
     if (height) *height = c->fb_h;
+    return GSX_OK;
+}
+
+int gsx_set_framebuffer_dev(gsx_ctx* c, void* rgba8_dev, uint64_t capacity_bytes) {
+    if (!c || (rgba8_dev && capacity_bytes == 0)) return GSX_E_INVALID;
+    int rc = set_device(c);
+    if (rc) return rc;
+    if ((rc = gsx_frame_finish(c))) return rc;     // the queued frame completes into the target it was started on
+    c->fb_ext = static_cast<uint8_t*>(rgba8_dev);
+    c->fb_ext_cap = rgba8_dev ? capacity_bytes : 0;
+    return GSX_OK;
+}
+
+int gsx_get_stream(gsx_ctx* c, void** hip_stream) {
+    if (!c || !hip_stream) return GSX_E_INVALID;
+    *hip_stream = static_cast<void*>(c->stream);
     return GSX_OK;
 }
 

@@ -158,8 +158,11 @@ struct gsx_ctx {
     uint16_t* pair_key[2] = {nullptr, nullptr};
     uint32_t* pair_val[2] = {nullptr, nullptr};
     uint64_t pair_cap = 0;
-    uint8_t* fb = nullptr;             // RGBA8 width*height
+    uint8_t* fb = nullptr;             // RGBA8 width*height (the library's own framebuffer)
     uint64_t fb_cap = 0;
+    uint8_t* fb_ext = nullptr;         // caller-owned render target (gsx_set_framebuffer_dev), nullptr = use fb
+    uint64_t fb_ext_cap = 0;
+    uint8_t* fb_cur = nullptr;         // where the queued / last frame was rendered
     uint32_t fb_w = 0, fb_h = 0;
     uint32_t* pair_ws = nullptr;       // radix workspace of the pair sort
     uint64_t pair_ws_words = 0;

@@ -780,13 +780,13 @@ static int launch_iteration(gsx_ctx* c, uint32_t iter, uint32_t window, bool fir
     const uint32_t fi = first ? 1u : 0u;
     if (f.mode == 0)
         hipLaunchKernelGGL(k_raster<0>, dim3(f.n_tiles), dim3(GSX_RASTER_NT), 0, c->stream, c->pair_key[cur], c->pair_val[cur], c->rank_rec, iter, vp,
-                           fi, c->tile_state, c->live_bits, c->accum, c->ctl, c->aux, c->fb);
+                           fi, c->tile_state, c->live_bits, c->accum, c->ctl, c->aux, c->fb_cur);
     else if (f.mode == 1)
         hipLaunchKernelGGL(k_raster<1>, dim3(f.n_tiles), dim3(GSX_RASTER_NT), 0, c->stream, c->pair_key[cur], c->pair_val[cur], c->rank_rec, iter, vp,
-                           fi, c->tile_state, c->live_bits, c->accum, c->ctl, c->aux, c->fb);
+                           fi, c->tile_state, c->live_bits, c->accum, c->ctl, c->aux, c->fb_cur);
     else
         hipLaunchKernelGGL(k_raster<2>, dim3(f.n_tiles), dim3(GSX_RASTER_NT), 0, c->stream, c->pair_key[cur], c->pair_val[cur], c->rank_rec, iter, vp,
-                           fi, c->tile_state, c->live_bits, c->accum, c->ctl, c->aux, c->fb);
+                           fi, c->tile_state, c->live_bits, c->accum, c->ctl, c->aux, c->fb_cur);
     if (c->profiling && iter < GSX_MAX_SCHED && !f.continuing) GSX_HIP(c, hipEventRecord(c->ev[EV_IT0 + 2 * iter + 1], c->stream));
     return GSX_OK;
 }
@@ -824,10 +824,20 @@ int gsx_launch_render(gsx_ctx* c, const gsx_uniforms* u, uint32_t w, uint32_t h,
     const uint32_t m_cap = c->m_cap;
 
     int rc;
-    if ((rc = ensure(c, &c->fb, &c->fb_cap, static_cast<uint64_t>(w) * h * 4)) != GSX_OK) return rc;
-    if (c->fb_w != w || c->fb_h != h) {
-        GSX_HIP(c, hipMemsetAsync(c->fb, 0, static_cast<uint64_t>(w) * h * 4, c->stream));
+    if (c->fb_ext) {
+        if (c->fb_ext_cap < static_cast<uint64_t>(w) * h * 4) {
+            c->err = "render target set with gsx_set_framebuffer_dev is smaller than width*height*4 bytes";
+            return GSX_E_INVALID;
+        }
+        c->fb_cur = c->fb_ext;
         c->fb_w = w; c->fb_h = h;
+    } else {
+        if ((rc = ensure(c, &c->fb, &c->fb_cap, static_cast<uint64_t>(w) * h * 4)) != GSX_OK) return rc;
+        if (c->fb_w != w || c->fb_h != h || c->fb_cur != c->fb) {
+            GSX_HIP(c, hipMemsetAsync(c->fb, 0, static_cast<uint64_t>(w) * h * 4, c->stream));
+            c->fb_w = w; c->fb_h = h;
+        }
+        c->fb_cur = c->fb;
     }
     if ((rc = ensure(c, &c->tile_state, &c->tile_state_cap, static_cast<uint64_t>(n_tiles) + 2)) != GSX_OK) return rc;
     if ((rc = ensure(c, &c->accum, &c->accum_cap, static_cast<uint64_t>(n_tiles) * GSX_TILE_W * GSX_TILE_H)) != GSX_OK) return rc;

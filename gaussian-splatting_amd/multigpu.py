@@ -47,3 +47,71 @@ def compose_bands(frames, bands, width):
         if r and y1 > y0:
             out[y0 * row:y1 * row] = frames[r][y0 * row:y1 * row]
     return out
+
+
+class BatchedFrameGather:
+    """View-batch sharding, the exchange step (cfg 4): every rank renders its views straight into the
+    slots of a batch buffer and, once `batch_frames` frames are complete, the whole batch goes to rank 0 in ONE
+    gather (direct sends, each peer on its own xGMI link).  Two batch buffers alternate, and the gather is started
+    asynchronously, so the next batch is rendered while RCCL moves the previous one.
+
+    `stream` (optional): a torch.cuda stream the renderer queues its work on (torch.cuda.ExternalStream of the
+    library's HIP stream).  The gather is then ordered behind the frames already queued on it, and re-using a
+    batch buffer makes that stream (not the host) wait for the gather that still reads it.  Without a stream
+    (gloo / CPU tensors) the waits are host-side.
+
+    Per frame i (0, 1, 2 ... of this rank):  t = slot(i) -> render into t -> frame_done(i) once frame i has been
+    queued completely.  finish() sends the last, possibly partial, batch and waits for everything."""
+
+    def __init__(self, dist, rank, world, frame_bytes, batch_frames, device, stream=None):
+        import torch
+        self.dist, self.rank, self.world = dist, rank, world
+        self.frame_bytes, self.batch_frames, self.stream = frame_bytes, batch_frames, stream
+        self.batches = [torch.zeros(batch_frames * frame_bytes, dtype=torch.uint8, device=device) for _ in range(2)]
+        self.recv = [[torch.zeros_like(b) for _ in range(world)] if rank == 0 else None for b in self.batches]
+        self.work = [None, None]
+        self.sent = [False, False]          # batch holds frames that have not been gathered yet
+        self.gathers = 0
+
+    def _ctx(self):
+        import contextlib
+        import torch
+        return torch.cuda.stream(self.stream) if self.stream is not None else contextlib.nullcontext()
+
+    def _wait(self, b):
+        if self.work[b] is not None:
+            with self._ctx():
+                self.work[b].wait()          # nccl: the current stream waits; gloo: the host waits
+            self.work[b] = None
+
+    def _start(self, b):
+        with self._ctx():
+            self.work[b] = self.dist.gather(self.batches[b], self.recv[b], dst=0, async_op=True)
+        self.sent[b] = False
+        self.gathers += 1
+
+    def slot(self, i):
+        """Device memory frame i is rendered into (a view of the batch buffer)."""
+        b, s = (i // self.batch_frames) % 2, i % self.batch_frames
+        if s == 0:
+            self._wait(b)                    # the gather started two batches ago still reads this buffer
+        self.sent[b] = True
+        return self.batches[b][s * self.frame_bytes:(s + 1) * self.frame_bytes]
+
+    def frame_done(self, i):
+        if i % self.batch_frames == self.batch_frames - 1:
+            self._start((i // self.batch_frames) % 2)
+
+    def finish(self):
+        for b in range(2):
+            if self.sent[b]:
+                self._start(b)
+        for b in range(2):
+            self._wait(b)
+
+    def frames_on_rank0(self, b):
+        """rank 0: [rank][slot] views of the batch buffer b received last (None elsewhere)."""
+        if self.rank != 0:
+            return None
+        fb = self.frame_bytes
+        return [[t[s * fb:(s + 1) * fb] for s in range(self.batch_frames)] for t in self.recv[b]]

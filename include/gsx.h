@@ -174,6 +174,18 @@ int gsx_render(gsx_ctx* ctx, const gsx_uniforms* u, uint32_t width, uint32_t hei
 /* Device pointer of the RGBA8 frame (valid until the next gsx_render with another size or gsx_destroy;
  * contents complete after gsx_sync, see gsx_render). */
 int gsx_get_framebuffer_dev(gsx_ctx* ctx, const void** rgba8_dev, uint32_t* width, uint32_t* height);
+/* Render target in caller-owned device memory (the counterpart of the swap-chain texture view the reference's
+ * render pass is given, renderer.cpp:132-176 / main.cpp:243-252).  Completes the queued frame into the current
+ * target first (including its on-demand iterations), then directs every following gsx_render to rgba8_dev, which
+ * must hold width*height*4 bytes of each frame rendered into it (capacity_bytes is checked per frame ->
+ * GSX_E_INVALID).  NULL returns to the library's own framebuffer.  The caller keeps the memory alive until the
+ * target is changed again or the context is destroyed; rows outside a rendered band are left untouched.
+ * Used by the multi-GPU view batches: each rank renders straight into its slot of the batch that RCCL gathers. */
+int gsx_set_framebuffer_dev(gsx_ctx* ctx, void* rgba8_dev, uint64_t capacity_bytes);
+/* The HIP stream (hipStream_t) every call on this context is queued on, for callers that order their own device
+ * work or collectives against the frames (e.g. torch.cuda.ExternalStream + RCCL).  No reference counterpart:
+ * the reference's queue is the wgpu::Queue handed to SplatMesh::initialize (SplatMesh.h:72). */
+int gsx_get_stream(gsx_ctx* ctx, void** hip_stream);
 
 /* ---- host-only helpers (no GPU touched): the load-time half of ResourceManager and
  * the scene-graph math that produces the path's inputs. ---- */

@@ -52,6 +52,23 @@ got = mg.gather_to_rank0(dist, fb, rank, world)
 if rank == 0:
     whole = mg.compose_bands(got, bands, W).numpy()
     ok &= bool(np.array_equal(whole, render(1).reshape(-1)))
+# --- batched asynchronous gather (bench.py at N > 1): 7 frames per rank in batches of 3, double-buffered ---
+FB, B, NF = 64, 3, 7
+def frame(r, i):
+    return torch.full((FB,), (17 * r + 3 * i + 1) % 251, dtype=torch.uint8)
+bg = mg.BatchedFrameGather(dist, rank, world, FB, B, "cpu")
+for i in range(NF):
+    bg.slot(i).copy_(frame(rank, i))
+    bg.frame_done(i)
+bg.finish()
+ok &= bg.gathers == 3 and all(w is None for w in bg.work)
+if rank == 0:
+    # frames 3..5 went through buffer 1, frame 6 (partial batch) through buffer 0 slot 0 on top of frames 0..2
+    for r in range(world):
+        got1 = [int(t[0]) for t in bg.frames_on_rank0(1)[r]]
+        ok &= got1 == [int(frame(r, i)[0]) for i in (3, 4, 5)]
+        got0 = [int(t[0]) for t in bg.frames_on_rank0(0)[r]]
+        ok &= got0 == [int(frame(r, 6)[0]), int(frame(r, 1)[0]), int(frame(r, 2)[0])]
     print("RESULT", "OK" if ok else "MISMATCH")
 dist.barrier()
 dist.destroy_process_group()

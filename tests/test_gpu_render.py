@@ -354,3 +354,54 @@ def test_frames_queued_back_to_back(gsx_fresh, pkg, oracle, synth):
     assert sum(launches.values()) == 6 and all(v > 0.0 for v in means.values())
     passes = gsx.timings()["sort_passes"]
     assert sorted(launches) == list(range(min(passes, 6)))   # the sampled pass rotates frame by frame
+
+
+def test_render_into_caller_owned_target(gsx_fresh, pkg, oracle, synth):
+    # gsx_set_framebuffer_dev: frames go straight into caller-owned device memory (the slots of the multi-GPU view
+    # batches); byte-identical to the library's own framebuffer, nothing written past width*height*4
+    import torch
+    gsx = gsx_fresh
+    w, h = 256, 192
+    nbytes = w * h * 4
+    splats = scene(oracle, synth, 3000, seed=2)
+    view, proj, cam = camera(oracle, w, h, steps=1)
+    u = pkg.make_uniforms(proj, view)
+    gsx.upload(splats)
+    gsx.sort(cam)
+    img = gsx.render(u, w, h).copy()
+    buf = torch.full((2 * nbytes + 256,), 7, dtype=torch.uint8, device="cuda:0")
+    torch.cuda.synchronize()
+    for slot in (1, 0):                                       # two slots of one batch buffer, like bench.py at N > 1
+        gsx.set_framebuffer_dev(buf.data_ptr() + slot * nbytes, nbytes)
+        gsx.sort(cam, download=False)
+        gsx.render(u, w, h, download=False)
+    gsx.set_framebuffer_dev(None)                             # completes the queued frame into its slot
+    gsx.sync()
+    host = buf.cpu().numpy()
+    for slot in (0, 1):
+        assert np.array_equal(host[slot * nbytes:(slot + 1) * nbytes].reshape(h, w, 4), img)
+    assert np.all(host[2 * nbytes:] == 7)
+    # the library's stream is a usable torch stream: work queued on it is ordered behind the frame
+    ext = torch.cuda.ExternalStream(gsx.stream(), device=torch.device("cuda", 0))
+    gsx.set_framebuffer_dev(buf.data_ptr(), nbytes)
+    gsx.render(u, w, h, download=False)
+    gsx.set_framebuffer_dev(None)
+    with torch.cuda.stream(ext):
+        copy = buf[:nbytes].clone()
+    ext.synchronize()
+    assert np.array_equal(copy.cpu().numpy().reshape(h, w, 4), img)
+    # a target that is too small is rejected, and the context keeps working on its own framebuffer afterwards
+    gsx.set_framebuffer_dev(buf.data_ptr(), nbytes - 4)
+    with pytest.raises(pkg.GsxError):
+        gsx.render(u, w, h, download=False)
+    gsx.set_framebuffer_dev(None)
+    assert np.array_equal(gsx.render(u, w, h), img)
+    # band into an external target leaves the other rows alone
+    buf.fill_(9)
+    torch.cuda.synchronize()
+    gsx.set_framebuffer_dev(buf.data_ptr(), nbytes)
+    gsx.render(u, w, h, 32, 112, download=False)
+    gsx.set_framebuffer_dev(None)
+    gsx.sync()
+    band = buf[:nbytes].cpu().numpy().reshape(h, w, 4)
+    assert np.array_equal(band[32:112], img[32:112]) and np.all(band[:32] == 9) and np.all(band[112:] == 9)

@@ -1,11 +1,15 @@
 #!/usr/bin/env python3
 """Print the last N kernel launches of a rocprofv3 --kernel-trace run in start order with duration and
-the idle gap before each: tools/ktrace.py <dir> [N]"""
+the idle gap before each: tools/ktrace.py <dir> [N [start_fraction]]"""
 import csv, glob, sys
 f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 60
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
-rows = rows[-n:]
+if len(sys.argv) > 3:                      # start at this fraction of the trace instead of taking the tail
+    at = int(len(rows) * float(sys.argv[3]))
+    rows = rows[at:at + n]
+else:
+    rows = rows[-n:]
 prev = None
 t0 = int(rows[0]["Start_Timestamp"])
 for r in rows:
