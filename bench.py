@@ -10,7 +10,8 @@ data already resident in HBM: depth keys -> stable radix sort -> projection ->
 near-to-far iterations of (occlusion-aware tile binning -> pair sort -> tile raster)
 into a device RGBA8 framebuffer (no readback).
 At N > 1 the path shards by camera view over a replicated splat set (weak
-scaling: a step is a batch of N views, rank r renders view r of the pose set) and the finished frames are
+scaling: a step is a batch of N views, one per rank, every rank at the pose of the N = 1 run so that the per-GPU work is
+fixed; --distinct-views: rank r renders pose r of the pose set) and the finished frames are
 gathered to rank 0 with RCCL inside the timed region: every rank renders into the
 slots of a batch buffer and each full batch of 8 frames goes out in one asynchronous
 gather while the next batch is rendered (multigpu.BatchedFrameGather).
@@ -108,6 +109,7 @@ def main():
     ap.add_argument("--scene", default="clustered")
     ap.add_argument("--cpu-frames", type=int, default=20, help="frames of the CPU baseline (0 = skip)")
     ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--distinct-views", action="store_true", help="N > 1: rank r renders pose r instead of the N = 1 pose")
     ap.add_argument("--gather-batch", type=int, default=8, help="frames per RCCL gather at N > 1")
     ap.add_argument("--opt", action="append", default=[], help="name=value for gsx_set_option (A/B runs; not used by the driver)")
     a = ap.parse_args()
@@ -141,11 +143,14 @@ def main():
     splats = scene.raw_to_splats(pkg, raw, center=False)      # host half of ResourceManager (libgsx, C++)
     W, H = a.width, a.height
     views = orbit_views(pkg, 64, W, H)
-    # view-batch sharding (weak scaling): a step of the job is a batch of N views, one per GPU; rank r renders view r of the
-    # pose set at every step, so the per-GPU work is the N = 1 workload whatever N is (independent units, no data-path
-    # collective until the finished frames are gathered)
+    # view-batch sharding (weak scaling): a step of the job is a batch of N views, one per GPU (independent units, no
+    # data-path collective until the finished frames are gathered)
     mg = importlib.import_module("gaussian_splatting_amd.multigpu")
-    my_views = [views[mg.shard_views(len(views), rank, max(world, 1))[0]]]
+    # Poses differ a lot in cost on this scene (0.41 .. 0.74 ms over the first 8, DESIGN.md section 5: tile pairs, and a camera
+    # inside the scene box needs a 4th radix pass), which would show up as a scaling loss that has nothing to do with N.
+    # Weak scaling wants the per-GPU work fixed, so by default every rank renders the pose of the N = 1 run into its own
+    # frame buffers; --distinct-views gives rank r pose r of the set instead.
+    my_views = [views[mg.shard_views(len(views), rank, max(world, 1))[0] if a.distinct_views else 0]]
     g = pkg.Gsx(local_rank)
     g.upload(splats)
     for o in a.opt:
@@ -258,6 +263,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"cfg2: {n}-splat clustered synthetic scene, single view {W}x{H} per step",
                        "splats": n, "width": W, "height": H, "views_per_step_per_gpu": 1,
+                       "poses": "rank r renders pose r" if a.distinct_views else "every rank renders the N=1 pose (fixed per-GPU work)",
                        "sharding": "camera views over replicated splats" + ("" if a.no_gather or world == 1 else f" + RCCL framebuffer gather to rank 0 in batches of {a.gather_batch} frames")},
             "fps_1080p": K * world / elapsed,
             "sort_only_splats_per_s": n / (keysort_ms * 1e-3),
