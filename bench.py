@@ -93,6 +93,19 @@ def cpu_baseline(splats, views, n_frames):
     return splats.shape[0] * n_frames / secs, secs
 
 
+def cpu_baseline_parallel(splats, views, n_frames, threads):
+    """Multi-threaded stand-in for the reference's PARALLEL build (tbb::task_arena(8) + std::sort(par), SplatMesh.h:97-103):
+    libstdc++ parallel-mode sort on `threads` OpenMP threads (oracle/orc_parsort.cpp; the image has no TBB headers)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import orc
+    O = orc.Oracle()
+    idx = np.arange(splats.shape[0], dtype=np.uint32)
+    secs = 0.0
+    for f in range(n_frames):
+        secs += O.sort_reference_port_parallel(splats, views[f % len(views)][2], idx, threads)
+    return splats.shape[0] * n_frames / secs, secs
+
+
 def _dbg(msg):
     if os.environ.get("GSX_BENCH_DEBUG"):
         print(f"[bench {time.perf_counter():.3f}] {msg}", file=sys.stderr, flush=True)
@@ -287,6 +300,16 @@ def main():
                                    "sample": f"{a.cpu_frames} consecutive frames of the full {n}-splat sortSplats "
                                              f"(distances alloc + key loop + std::sort, {secs:.1f} s of CPU; sort only, the "
                                              "reference has no CPU raster)"}
+            try:
+                threads = 8                                      # the reference's fixed arena size (SplatMesh.h:98)
+                v, secs = cpu_baseline_parallel(splats, views, a.cpu_frames, threads)
+                out["cpu_baseline_parallel"] = {"value": v, "unit": "splats/s", "cores": threads, "kind": "port",
+                                                "sample": f"{a.cpu_frames} consecutive frames of the full {n}-splat sortSplats, "
+                                                          f"{secs:.1f} s wall; libstdc++ parallel-mode sort (OpenMP) with the "
+                                                          "reference's comparator on the reference's 8 threads -- NOT TBB: "
+                                                          "the image has no TBB headers, so the PARALLEL build cannot be compiled"}
+            except OSError as e:                                 # liborc_par.so / libgomp missing: say so, keep the line
+                out["cpu_baseline_parallel"] = {"value": None, "note": f"unavailable: {e}"}
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     _dbg("closing")

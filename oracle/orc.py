@@ -95,6 +95,16 @@ class Oracle:
         return self.lib.orc_sort_reference_port(_opt(splats), C.c_uint64(splats.shape[0]), _opt(idx),
                                                 C.c_uint64(len(idx)), _opt(cam))
 
+    def sort_reference_port_parallel(self, splats, cam, idx, threads=8):
+        """Multi-threaded port (liborc_par.so: libstdc++ parallel mode, the image has no TBB headers) of the reference's
+        PARALLEL build, SplatMesh.h:97-103.  In-place on idx; returns seconds."""
+        if not hasattr(self, "par"):
+            self.par = C.CDLL(os.path.join(_HERE, "liborc_par.so"))
+            self.par.orc_sort_reference_port_parallel.restype = C.c_double
+        cam = np.ascontiguousarray(cam, np.float32)
+        return self.par.orc_sort_reference_port_parallel(_opt(splats), C.c_uint64(splats.shape[0]), _opt(idx),
+                                                         C.c_uint64(len(idx)), _opt(cam), C.c_int(threads))
+
     # -- camera --
     def perspective(self, fov_deg=45.0, aspect=1.0, near=0.1, far=100.0):
         out = np.empty(16, np.float32)

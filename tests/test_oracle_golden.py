@@ -86,6 +86,18 @@ def test_sort_reference_port_matches_contract_keys(oracle, synth):
     assert np.array_equal(bits(keys[idx]), bits(keys[oracle.sort_contract(splats, cam)]))
 
 
+def test_sort_reference_port_parallel_matches_contract_keys(oracle, synth):
+    """The multi-threaded baseline port (stand-in for the reference's PARALLEL build) yields the same key sequence."""
+    n = 200_000                                        # above libstdc++'s parallel-mode threshold, so threads really run
+    splats = oracle.raw_to_splat(synth.uniform_cloud(n, seed=2))
+    cam = np.array([0.3, -0.2, 5.0], np.float32)
+    idx = np.arange(n, dtype=np.uint32)
+    secs = oracle.sort_reference_port_parallel(splats, cam, idx, threads=4)
+    assert secs > 0 and np.array_equal(np.sort(idx), np.arange(n, dtype=np.uint32))
+    keys = oracle.distance_keys(splats, cam)
+    assert np.array_equal(bits(keys[idx]), bits(keys[oracle.sort_contract(splats, cam)]))
+
+
 def test_sort_contract_sublist_and_empty(oracle, synth):
     splats = oracle.raw_to_splat(synth.uniform_cloud(300, seed=5))
     cam = np.array([0, 0, 5], np.float32)
