@@ -233,6 +233,12 @@ int gsx_get_timings(gsx_ctx* c, gsx_timings* out) {
     if (c->sorted_valid) {
         t.sort_passes = c->sort_passes;
         t.sort_launches = 3 * c->sort_passes - 1;   // pass 0's count is fused into the key kernel
+        if (c->sort_gated) {                        // the gated top-digit pass: launched (+ its copy), executed only if a key needed it
+            uint32_t wide = 0;
+            GSX_HIP(c, hipMemcpy(&wide, &c->flags->wide_m, sizeof wide, hipMemcpyDeviceToHost));
+            t.sort_launches += 1;                   // the gated copy
+            if (!wide) --t.sort_passes;
+        }
     }
     *out = t;
     return GSX_OK;

@@ -66,7 +66,7 @@ struct GsxFrameState {
 struct GsxDevFlags {
     uint32_t reserved0;
     uint32_t asym_cov;       // upload saw a non-symmetric covariance block
-    uint32_t reserved1;
+    uint32_t wide_m;         // key count of the gated top-digit pass of the depth sort: 0, or m once a key needed the top bits
     uint32_t bad_index;      // a selection list named an id >= n
     uint32_t key_bound;      // a depth key fell outside the host-computed [dmin, dmax] bound (NaN position?)
     uint32_t pad[3];
@@ -143,6 +143,7 @@ struct gsx_ctx {
     uint32_t* perm[2] = {nullptr, nullptr};
     uint32_t perm_cur = 0;             // perm[perm_cur] holds the latest permutation
     uint32_t sort_passes = 0;
+    bool sort_gated = false;   // the latest depth sort queued a gated top-digit pass (counted in sort_passes)
     uint32_t sort_slots = 1024, pair_slots = 1024;   // resident workgroups of the scatter kernels (CUs x blocks/CU)
     float cam[3] = {0, 0, 0};
     float aabb_min[3] = {0, 0, 0}, aabb_max[3] = {0, 0, 0};  // of the uploaded positions

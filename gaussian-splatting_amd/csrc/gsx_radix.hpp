@@ -146,6 +146,7 @@ __global__ __launch_bounds__(NT) void k_radix_hist(const KeyT* __restrict__ keys
     __shared__ uint32_t s_hist[GSX_RADIX_MAX_DIGITS * GSX_HREP];
     const uint32_t nd = 1u << bits, mask = nd - 1u;
     const uint32_t count = *count_ptr;
+    if (count == 0u) return;                 // (nothing to sort, or a gated pass that is switched off: the scatter returns too)
     const uint32_t n_cols = gsx_n_cols(count, tile, max_cols);
     for (uint32_t col = gsx_logical_block(); col < n_cols; col += gridDim.x) {
         gsx_hist_zero(s_hist, NT);
@@ -180,6 +181,7 @@ template <int DUMMY>
 __global__ __launch_bounds__(256) void k_radix_scan(uint32_t* __restrict__ cnt, const uint32_t* __restrict__ count_ptr, uint32_t tile,
                                                    uint32_t max_cols, uint32_t* __restrict__ totals) {
     __shared__ uint32_t s_tmp[4];
+    if (*count_ptr == 0u) return;
     const uint32_t g = gsx_n_cols(*count_ptr, tile, max_cols);
     uint32_t* row = cnt + static_cast<uint64_t>(blockIdx.x) * g;
     constexpr int PER = GSX_RADIX_MAX_BLOCKS / 256;   // 8 consecutive entries per thread

@@ -67,12 +67,13 @@ template <bool IOTA>
 __global__ __launch_bounds__(GSX_SORT_NT) void k_keygen_hist0(const float4* __restrict__ pos4, const uint32_t* __restrict__ sel,
                                                               const uint32_t* __restrict__ m_ptr, float cx, float cy, float cz,
                                                               uint32_t key_lo, uint32_t key_span, uint32_t shift, uint32_t bits,
-                                                              uint32_t* __restrict__ keys, uint32_t* __restrict__ cnt, uint32_t max_cols,
+                                                              uint32_t wide_mask, uint32_t* __restrict__ keys, uint32_t* __restrict__ cnt, uint32_t max_cols,
                                                               GsxDevFlags* __restrict__ flags) {
     __shared__ uint32_t s_hist[GSX_RADIX_MAX_DIGITS * GSX_HREP];
     const uint32_t nd = 1u << bits, mask = nd - 1u;
     const uint32_t m = *m_ptr;
     const uint32_t n_cols = gsx_n_cols(m, GSX_SORT_TILE, max_cols);
+    uint32_t top = 0;                                  // OR of the key bits above the ungated passes
     for (uint32_t col = gsx_logical_block(); col < n_cols; col += gridDim.x) {
     gsx_hist_zero(s_hist, GSX_SORT_NT);
     uint32_t begin, end;
@@ -98,12 +99,23 @@ __global__ __launch_bounds__(GSX_SORT_NT) void k_keygen_hist0(const float4* __re
                 rel = (key < key_lo) ? 0u : key_span;
             }
             keys[k] = rel;
+            top |= rel & wide_mask;
             gsx_hist_add(s_hist, (rel >> shift) & mask);
         }
     }
     gsx_hist_store(s_hist, nd, GSX_SORT_NT, cnt, n_cols, col);
     __syncthreads();
     }
+    // A key with bits above the ungated passes (a splat within ~2^-16 of the far bound's distance from the camera)
+    // switches the gated top-digit pass on: its kernels take their key count from wide_m.
+    if (top != 0u) atomicMax(&flags->wide_m, m);
+}
+
+// Gated copy of the permutation (the top-digit pass leaves it in a scratch array): count 0 = nothing to do.
+__global__ __launch_bounds__(512) void k_copy_gated(const uint32_t* __restrict__ count_ptr, const uint32_t* __restrict__ src,
+                                                    uint32_t* __restrict__ dst) {
+    const uint32_t n = *count_ptr;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) dst[i] = src[i];
 }
 
 // Distances only (parity aid for gsx_get_keys).
@@ -213,14 +225,24 @@ int gsx_launch_sort(gsx_ctx* c) {
     key_bounds(c, &key_lo, &key_span);
     uint32_t total_bits = 0;
     while (total_bits < 32 && (static_cast<uint64_t>(key_span) >> total_bits) != 0) ++total_bits;
-    const GsxRadixPlan plan = gsx_radix_plan(total_bits);
+    // A host bound wider than three full digits (the camera stands inside the scene box, so the nearest distance the
+    // host can promise is 0) does not buy a fourth full pass: the low 27 bits are sorted as usual and the top bits
+    // get a GATED pass whose kernels take their key count from flags->wide_m — 0 unless the key kernel met a key
+    // that uses those bits (a splat closer than ~2^-16 of the far bound).  Decided on the device, exact either way.
+    constexpr uint32_t LOW_BITS = 3 * GSX_RADIX_MAX_BITS;
+    const uint32_t top_bits = total_bits > LOW_BITS ? total_bits - LOW_BITS : 0u;
+    const GsxRadixPlan plan = gsx_radix_plan(top_bits ? LOW_BITS : total_bits);
+    const uint32_t wide_mask = top_bits ? ~((1u << LOW_BITS) - 1u) : 0u;
+    if (top_bits) GSX_HIP(c, hipMemsetAsync(&c->flags->wide_m, 0, sizeof(uint32_t), c->stream));
     if (c->profiling) GSX_HIP(c, hipEventRecord(c->ev[EV_KEY0], c->stream));
     if (c->sel_iota)
         hipLaunchKernelGGL(k_keygen_hist0<true>, dim3(g), dim3(GSX_SORT_NT), 0, c->stream, c->pos4, nullptr, c->m_dev, c->cam[0],
-                           c->cam[1], c->cam[2], key_lo, key_span, plan.shift[0], plan.bits[0], c->keys[0], c->sort_ws, cols, c->flags);
+                           c->cam[1], c->cam[2], key_lo, key_span, plan.shift[0], plan.bits[0], wide_mask, c->keys[0], c->sort_ws, cols,
+                           c->flags);
     else
         hipLaunchKernelGGL(k_keygen_hist0<false>, dim3(g), dim3(GSX_SORT_NT), 0, c->stream, c->pos4, c->sel_idx, c->m_dev, c->cam[0],
-                           c->cam[1], c->cam[2], key_lo, key_span, plan.shift[0], plan.bits[0], c->keys[0], c->sort_ws, cols, c->flags);
+                           c->cam[1], c->cam[2], key_lo, key_span, plan.shift[0], plan.bits[0], wide_mask, c->keys[0], c->sort_ws, cols,
+                           c->flags);
     if (c->profiling) GSX_HIP(c, hipEventRecord(c->ev[EV_KEY1], c->stream));
     uint32_t cur = 0;
     c->sampled_pass = (c->prof_level == 2 && plan.n_passes > 0) ? static_cast<int>(c->prof_frame % static_cast<uint32_t>(plan.n_passes)) : -1;
@@ -243,11 +265,20 @@ int gsx_launch_sort(gsx_ctx* c) {
                                                           cols, /*need_hist=*/!first, /*iota=*/first && c->sel_iota, e0, e1);
         cur ^= 1;
     }
+    if (top_bits) {   // gated top digit: result -> scratch values, then back (all four kernels see count 0 in the common case)
+        static_assert(EV_X0 + 2 * 3 + 1 < EV_X_END, "event slots of the gated pass");
+        launch_pass<uint32_t, GSX_SORT_NT, GSX_SORT_IPT>(c, c->stream, g, c->keys[cur], result, c->keys[cur ^ 1], c->vals[cur ^ 1],
+                                                          &c->flags->wide_m, LOW_BITS, top_bits, c->sort_ws, cols, /*need_hist=*/true,
+                                                          /*iota=*/false, c->profiling ? c->ev[EV_X0 + 6] : nullptr,
+                                                          c->profiling ? c->ev[EV_X0 + 7] : nullptr);
+        hipLaunchKernelGGL(k_copy_gated, dim3(g), dim3(512), 0, c->stream, &c->flags->wide_m, c->vals[cur ^ 1], result);
+    }
     c->perm_cur ^= 1u;
     if (c->profiling) GSX_HIP(c, hipEventRecord(c->ev[EV_SORT1], c->stream));
     GSX_HIP(c, hipGetLastError());
     c->sorted_valid = true;
-    c->sort_passes = static_cast<uint32_t>(plan.n_passes);
+    c->sort_passes = static_cast<uint32_t>(plan.n_passes) + (top_bits ? 1u : 0u);   // (the gated pass counts as launched)
+    c->sort_gated = top_bits != 0;
     return GSX_OK;
 }
 

@@ -353,7 +353,7 @@ def test_frames_queued_back_to_back(gsx_fresh, pkg, oracle, synth):
     means, launches = gsx.scatter_samples()
     assert sum(launches.values()) == 6 and all(v > 0.0 for v in means.values())
     passes = gsx.timings()["sort_passes"]
-    assert sorted(launches) == list(range(min(passes, 6)))   # the sampled pass rotates frame by frame
+    assert sorted(launches) == list(range(min(passes, 3)))   # the sampled pass rotates frame by frame over the ungated passes
 
 
 def test_render_into_caller_owned_target(gsx_fresh, pkg, oracle, synth):

@@ -90,6 +90,34 @@ def test_sort_wide_key_range(gsx, oracle):
     assert gsx.timings()["sort_passes"] == 4
 
 
+def test_sort_camera_inside_scene_box(gsx, oracle, synth):
+    """A camera inside the scene's bounding box: the host can only bound the nearest distance by 0, so the key range is
+    the full 31 bits.  The low 27 bits take three passes; the top digit is a gated pass that runs only when the key
+    kernel met a key that needs it (decided on the device).  Both outcomes must give the oracle's permutation."""
+    n = 200_000
+    splats = oracle.raw_to_splat(synth.clustered_cloud(n, seed=9))
+    lo, hi = splats[:, 12:15].min(axis=0), splats[:, 12:15].max(axis=0)
+    cam = (lo + (hi - lo) * np.array([0.45, 0.55, 0.5], np.float32)).astype(np.float32)
+    d = oracle.distance_keys(splats, cam)
+    assert d.min() > 1e-3 * d.max()                                   # nobody close enough to need the top digit
+    gsx.upload(splats)
+    assert np.array_equal(gsx.sort(cam), oracle.sort_contract(splats, cam))
+    assert gsx.timings()["sort_passes"] == 3                          # gated pass queued, found nothing to do
+    near = splats.copy()                                              # three splats at 0 .. 1e-6 from the camera
+    near[[5, 77_777, n - 1], 12:15] = cam + np.array([[1e-6, 0, 0], [0, 0, 0], [0, -3e-7, 2e-7]], np.float32)
+    gsx.upload(near)
+    assert np.array_equal(bits(gsx.keys(cam)), bits(oracle.distance_keys(near, cam)))
+    assert np.array_equal(gsx.sort(cam), oracle.sort_contract(near, cam))
+    assert gsx.timings()["sort_passes"] == 4                          # top digit executed
+    out = (hi + (hi - lo)).astype(np.float32)                         # outside the box again: the gate must be off, not stale
+    assert np.array_equal(gsx.sort(out), oracle.sort_contract(near, out))
+    assert gsx.timings()["sort_passes"] == 3
+    assert np.array_equal(gsx.sort(cam), oracle.sort_contract(near, cam))
+    gsx.upload(splats)                                                # and a frame after a wide one starts from a cleared gate
+    assert np.array_equal(gsx.sort(cam), oracle.sort_contract(splats, cam))
+    assert gsx.timings()["sort_passes"] == 3
+
+
 def test_sort_is_repeatable_and_view_dependent(gsx, oracle, synth):
     splats = oracle.raw_to_splat(synth.clustered_cloud(30000, seed=8))
     gsx.upload(splats)
