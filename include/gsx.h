@@ -84,7 +84,8 @@ typedef struct gsx_timings {
     float bin_ms;
     float raster_ms;
     float total_ms;    /* first to last recorded event of the frame */
-    uint32_t sort_passes;   /* radix passes actually executed (constant-digit passes are skipped) */
+    uint32_t sort_passes;   /* radix passes actually executed (digits the frame's key range does not reach are never
+                               planned; the gated top-digit pass counts only when a key switched it on) */
     uint32_t sort_launches; /* kernel launches inside sort_ms */
     uint64_t tile_pairs;    /* (tile, splat) pairs the binner emitted (after occlusion culling) */
     uint32_t render_iters;  /* near -> far iterations of the frame that emitted pairs */
