@@ -190,6 +190,10 @@ struct gsx_ctx {
     // ranks (from the near end) earlier frames needed before every tile was retired; ~0u = the whole selection
     uint32_t need_hist[8] = {};
     uint32_t need_pos = 0;             // frames recorded so far (ring position = need_pos % 8)
+    uint64_t rest_pairs = ~0ull;       // (tile, splat) pairs the last frame emitted behind its first window (~0 = unknown)
+    float last_cam[3] = {0, 0, 0};     // camera of the last rendered frame (history is only trusted for a similar pose)
+    bool have_last_cam = false;
+    bool rest_merged = false;          // the last schedule took everything behind the first window in one iteration
     float density0 = 0.0f;             // (tile, splat) pairs per rank in the last frame's first window (0 = unknown)
     hipEvent_t frame_ev = nullptr;
     bool frame_pending = false;

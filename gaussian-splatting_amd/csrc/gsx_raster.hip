@@ -898,9 +898,31 @@ int gsx_launch_render(gsx_ctx* c, const gsx_uniforms* u, uint32_t w, uint32_t h,
         if (wd < win) win = wd;
     }
     const uint64_t growth = c->opt_chunk_growth ? c->opt_chunk_growth : 4u;
+    // Behind a dense foreground the first window is small and the growth rule would queue two more iterations for the few
+    // tiles it leaves live; when the last frame emitted only a few pairs behind its first window, one iteration takes all
+    // the rest (an iteration's fixed cost is ~60 us; the live-tile mask keeps its pair count small whatever its length).
+    // Hysteresis: the merged schedule emits somewhat more of those pairs than the split one it replaces.  Only for a steady
+    // camera (moved less than a tenth of its distance to the scene centre since the last frame, as in an orbit): after a
+    // jump to another pose the last frame says nothing about this one, and a mispredicted merge costs more than it saves
+    // (measured on the 64-pose set of cfg 4: 1.35 -> 1.47 ms per view without this test).
+    bool steady = false;
+    if (c->have_last_cam && c->aabb_valid) {
+        float d2 = 0.0f, r2 = 0.0f;
+        for (int k = 0; k < 3; ++k) {
+            const float d = c->cam[k] - c->last_cam[k], r = c->cam[k] - 0.5f * (c->aabb_min[k] + c->aabb_max[k]);
+            d2 += d * d;
+            r2 += r * r;
+        }
+        steady = d2 <= 0.01f * r2;
+    }
+    for (int k = 0; k < 3; ++k) c->last_cam[k] = c->cam[k];
+    c->have_last_cam = true;
+    const bool merge_rest = steady && !c->opt_chunk_growth && !c->opt_no_history && c->rest_pairs != ~0ull &&
+                            c->rest_pairs <= (c->rest_merged ? (4ull << 20) : (2ull << 20)) && c->rest_pairs * 4u < c->pair_cap;
+    c->rest_merged = merge_rest;
     do {
         uint64_t wnd = win;
-        if (n_iters + 1 == GSX_MAX_SCHED || covered + wnd + wnd / 2 >= need) wnd = need - covered;   // last one takes the rest
+        if (n_iters + 1 == GSX_MAX_SCHED || covered + wnd + wnd / 2 >= need || (merge_rest && n_iters >= 1)) wnd = need - covered;   // last one takes the rest
         if ((rc = launch_iteration(c, n_iters, static_cast<uint32_t>(wnd), n_iters == 0)) != GSX_OK) return rc;
         covered += wnd;
         win *= growth;
@@ -960,6 +982,10 @@ int gsx_frame_finish(gsx_ctx* c) {
         if (h.live_tiles == 0u) rec = c->aux_host[16];    // every tile retired: the deepest rank any of them consumed
         else if (h.dead_at) rec = h.dead_at - 1u;
         c->need_hist[c->need_pos++ % 8u] = rec;
+    }
+    {
+        const uint64_t total = c->ctl_host->total_pairs, first = c->aux_host[2];
+        c->rest_pairs = total > first ? total - first : 0u;
     }
     c->tim.tile_pairs = c->ctl_host->total_pairs;
     c->tim.render_iters = c->ctl_host->iters_used;

@@ -259,6 +259,18 @@ def test_large_render_properties(gsx_fresh, pkg, oracle, synth):
     for _ in range(3):
         again = gsx.render(u, w, h)
         assert np.abs(again.astype(np.int32) - img.astype(np.int32)).max() <= 1
+    # (6) a steady camera INSIDE the cloud (dense foreground: small first window, and the schedule learns to take
+    #     everything behind it in one iteration): frames under the adapting schedule agree with the history-free frame
+    view2, proj2, cam2 = camera(oracle, w, h, steps=1, distance=2.0)
+    u2 = pkg.make_uniforms(proj2, view2)
+    gsx.set_option("no_history", 1)
+    gsx.sort(cam2)
+    inside = gsx.render(u2, w, h)
+    assert inside[..., :3].std() > 10
+    gsx.set_option("no_history", 0)
+    for _ in range(5):
+        again = gsx.render(u2, w, h)
+        assert np.abs(again.astype(np.int32) - inside.astype(np.int32)).max() <= 1
 
 
 def test_large_overlap_4k_bands(gsx_fresh, pkg, oracle, synth):
