@@ -113,7 +113,9 @@ int gsx_get_scatter_samples(gsx_ctx* ctx, double sum_ms[4], uint32_t launches[4]
  *   "pair_budget"   (tile, splat) pairs one near -> far iteration may emit (sizes the pair buffers,
  *                   12 bytes per pair); the device cuts iterations to fit and a frame that needs
  *                   more simply runs more iterations
- *   "chunk_first"   ranks of the first (nearest) iteration;  "chunk_growth"  window growth factor
+ *   "chunk_first"   ranks of the first (nearest) iteration;  "chunk_growth"  window growth factor (setting it also
+ *                   switches off the merged schedule: with a steady camera and few pairs behind the first window in the
+ *                   last frame, the default takes everything behind that window in one iteration)
  *   "no_history"    1 = always pre-queue iterations for the whole selection (default: only as many ranks as
  *                   the last 8 frames needed before every tile was saturated, +25 %; the rest runs on demand)
  * Unknown name -> GSX_E_INVALID. */
