@@ -93,6 +93,9 @@ def cfg4():
     us = [pkg.make_uniforms(v[1], v[0]) for v in views]
     with pkg.Gsx(0) as g:
         g.upload(splats)
+        for o in os.environ.get("GSX_OPTS", "").split():      # A/B runs: GSX_OPTS="no_history=1 chunk_first=262144"
+            k, val = o.split("=")
+            g.set_option(k, int(val))
         for rnd in range(2):
             t0 = time.perf_counter()
             for i, v in enumerate(views):
@@ -102,7 +105,7 @@ def cfg4():
             dt = (time.perf_counter() - t0) / len(views)
         t = g.timings()
     emit({"config": "cfg4 (one GPU's work for all 64 views)", "splats": n, "views": len(views), "ms_per_view": dt * 1e3,
-          "views_per_s": 1.0 / dt, "splats_per_s": n / dt, "sort_passes": t["sort_passes"]})
+          "views_per_s": 1.0 / dt, "splats_per_s": n / dt, "sort_passes": t["sort_passes"], "opts": os.environ.get("GSX_OPTS", "")})
 
 
 def cfg5():
