@@ -1,4 +1,5 @@
 // gsx_api.hip — the extern "C" entry points declared in include/gsx.h.
+#include <cstddef>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -36,8 +37,14 @@ int check_flags(gsx_ctx* c) {
     if (frc) return frc;
     GSX_HIP(c, hipMemcpyAsync(c->flags_host, c->flags, sizeof(GsxDevFlags), hipMemcpyDeviceToHost, c->stream));
     GSX_HIP(c, hipStreamSynchronize(c->stream));
-    if (c->flags_host->bad_index) { c->err = "selection list holds an id >= n"; return GSX_E_INVALID; }
-    if (c->flags_host->key_bound) { c->err = "device: a depth key left the scene's distance bound (non-finite position?)"; return GSX_E_INTERNAL; }
+    const bool bad_index = c->flags_host->bad_index != 0, key_bound = c->flags_host->key_bound != 0;
+    if (bad_index || key_bound) {
+        // reported once: the words are cleared so that the next (valid) selection / sort on this context succeeds
+        static_assert(offsetof(GsxDevFlags, key_bound) == offsetof(GsxDevFlags, bad_index) + 4, "bad_index and key_bound are adjacent");
+        GSX_HIP(c, hipMemsetAsync(&c->flags->bad_index, 0, 8, c->stream));
+    }
+    if (bad_index) { c->err = "selection list holds an id >= n"; return GSX_E_INVALID; }
+    if (key_bound) { c->err = "device: a depth key left the scene's distance bound (non-finite position?)"; return GSX_E_INTERNAL; }
     return GSX_OK;
 }
 
@@ -350,6 +357,15 @@ int gsx_set_lod_hc(gsx_ctx* c, const gsx_hc_flat* f) {
     const uint32_t n = f->n_nodes;
     for (uint32_t i = 0; i < n; ++i)
         if (f->parent[i] != 0xFFFFFFFFu && f->parent[i] >= n) { c->err = "hc: parent id out of range"; return GSX_E_INVALID; }
+    {   // k_emit_flags walks parent chains: a cycle (or parent[i] == i) would never end on the device
+        std::vector<uint32_t> seen(n, 0u);           // 0 = unvisited, n + 1 = known to reach a root, else 1 + the walk that found it
+        for (uint32_t i = 0; i < n; ++i) {
+            uint32_t a = i;
+            while (a != 0xFFFFFFFFu && seen[a] == 0u) { seen[a] = i + 1u; a = f->parent[a]; }
+            if (a != 0xFFFFFFFFu && seen[a] == i + 1u) { c->err = "hc: parent links form a cycle"; return GSX_E_INVALID; }
+            for (a = i; a != 0xFFFFFFFFu && seen[a] == i + 1u; a = f->parent[a]) seen[a] = n + 1u;
+        }
+    }
     std::vector<float> a(static_cast<size_t>(n) * 4);
     for (uint32_t i = 0; i < n; ++i) { a[4 * i] = f->error[i]; a[4 * i + 1] = f->weight[i]; a[4 * i + 2] = 0; a[4 * i + 3] = 0; }
     if ((rc = dev_alloc(c, &c->lod_a, n)) || (rc = dev_alloc(c, &c->lod_parent, n)) || (rc = dev_alloc(c, &c->lod_leaf, n))) return rc;

@@ -25,6 +25,8 @@ int gsx_host_convert_raw(const void* raw32, uint64_t n, int center, void* aos80_
         split.resize(n);
     } catch (const std::bad_alloc&) {
         return GSX_E_NOMEM;
+    } catch (const std::exception&) {      // e.g. std::length_error from an absurd element count: nothing crosses the C ABI
+        return GSX_E_INVALID;
     }
     for (uint64_t i = 0; i < n; ++i) split[i] = raw_to_split(raw[i]);
     if (center && n) center_splats(split);
@@ -42,6 +44,8 @@ int gsx_host_load_splat_file(const char* path, int center, void** aos80_out, uin
         split = loadSplatsRaw(path, center != 0);
     } catch (const std::bad_alloc&) {
         return GSX_E_NOMEM;
+    } catch (const std::exception&) {      // e.g. std::length_error from an absurd element count: nothing crosses the C ABI
+        return GSX_E_INVALID;
     }
     if (split.empty()) return GSX_OK;  // missing file == empty scene, like the reference
     Splat* out = static_cast<Splat*>(std::malloc(split.size() * sizeof(Splat)));
@@ -64,6 +68,8 @@ int gsx_host_load_ply_raw(const char* path, void** raw32_out, uint64_t* n_out) {
         st = load_ply_raw(path, raw);
     } catch (const std::bad_alloc&) {
         return GSX_E_NOMEM;
+    } catch (const std::exception&) {      // e.g. std::length_error from an absurd element count: nothing crosses the C ABI
+        return GSX_E_INVALID;
     }
     if (st == PlyStatus::CannotOpen) return GSX_OK;              // missing file == empty scene, like loadSplatsRaw
     if (st == PlyStatus::Unsupported) return GSX_E_UNSUPPORTED;
@@ -229,7 +235,7 @@ int gsx_host_lod_cut_depth(gsx_lod* l, uint32_t depth, uint32_t* idx_out, uint64
         if (l->kind == 1) ind = l->octree.get_indices_depth(depth);            // Octree.hpp:131-162
         else if (l->kind == 2) ind = l->hc.get_indices_depth(depth);            // HC.cpp:134-168
         else ind = l->grid.get_indices_error(depth, 0.0f);                      // GridHC.cpp:76-92
-    } catch (const std::bad_alloc&) { return GSX_E_NOMEM; }
+    } catch (const std::bad_alloc&) { return GSX_E_NOMEM; } catch (const std::exception&) { return GSX_E_INTERNAL; }
     *m_out = ind.size();
     if (idx_out) {
         if (capacity < ind.size()) return GSX_E_INVALID;
@@ -251,7 +257,7 @@ int gsx_host_lod_cut_camera(gsx_lod* l, const float world16[16], float fov_deg, 
         if (l->kind == 1) ind = l->octree.get_indices(cam, threshold);                         // Octree.cpp:189-216
         else if (l->kind == 2) ind = l->hc.get_indices(cam, threshold, HC::MetricWeights{});   // HC.cpp:100-132
         else ind = l->grid.get_indices(cam, threshold, HC::MetricWeights{});                   // GridHC.cpp:94-111
-    } catch (const std::bad_alloc&) { return GSX_E_NOMEM; }
+    } catch (const std::bad_alloc&) { return GSX_E_NOMEM; } catch (const std::exception&) { return GSX_E_INTERNAL; }
     *m_out = ind.size();
     if (idx_out) {
         if (capacity < ind.size()) return GSX_E_INVALID;

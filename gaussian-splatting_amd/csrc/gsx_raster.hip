@@ -627,7 +627,13 @@ __global__ __launch_bounds__(GSX_RASTER_NT) void k_raster(const uint16_t* __rest
                     const gsx_f2 dx = fx - sa.x;
                     const float dy = fy - sa.y;
                     const gsx_f2 u = sm.x * dx + sm.y * dy, v = sm.z * dx + sm.w * dy;
-                    const bool h0 = fabsf(u.x) <= cut && fabsf(v.x) <= cut, h1 = fabsf(u.y) <= cut && fabsf(v.y) <= cut;
+                    // A pixel is FROZEN at the first splat that leaves its transmittance below GSX_T_EPS: nothing behind
+                    // that splat contributes, whenever the wave / tile happens to stop.  This makes the frame a pure
+                    // function of (scene, permutation, uniforms): iteration windows, the history-driven schedule, the
+                    // pair budget and the band a tile is rendered in only decide WHEN work is skipped, never what a
+                    // pixel holds (skipped contribution < GSX_T_EPS per channel = 0.13/255).
+                    const bool h0 = fabsf(u.x) <= cut && fabsf(v.x) <= cut && T.x >= GSX_T_EPS,
+                               h1 = fabsf(u.y) <= cut && fabsf(v.y) <= cut && T.y >= GSX_T_EPS;
 #ifdef GSX_DEBUG_COUNT
                     ++dbg_shaded;
                     dbg_hits += __popcll(__builtin_amdgcn_ballot_w64(h0)) + __popcll(__builtin_amdgcn_ballot_w64(h1));

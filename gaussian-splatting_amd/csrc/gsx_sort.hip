@@ -1,5 +1,5 @@
 // gsx_sort.hip — scene upload (AoS -> SoA), depth-key generation fused with the
-// digit histograms, the sort plan, and the onesweep radix passes.
+// digit histograms, the sort plan, and the stable LSD radix passes (gsx_radix.hpp).
 //
 // Reference path replaced: SplatMesh::sortSplats (SplatMesh.h:84-114) and the
 // per-frame index upload (SplatMesh.h:56-57).

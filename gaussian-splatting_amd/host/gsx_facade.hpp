@@ -20,6 +20,8 @@
 // which is the "device framebuffer readback" the optional viewer front end shows.
 #pragma once
 #include <cstring>
+#include <functional>
+#include <iostream>
 #include <memory>
 #include <numeric>
 #include <stdexcept>
@@ -31,6 +33,29 @@
 #include "gsx_ply.hpp"
 #include "gsx_scene.hpp"
 #include "gsx_splat.hpp"
+
+// ---- the window type Renderer::init takes (renderer.hpp:28, renderer.cpp:3-5) ----
+// A viewer build defines GSX_FACADE_WITH_GLFW and gets the real <GLFW/glfw3.h>.  Headless (the MI355X box has no
+// display): GLFWwindow is a plain size record and the three GLFW calls the init path makes (main.cpp:162-163,205;
+// renderer.cpp:5) exist with the same signatures, so `m_window = glfwCreateWindow(w, h, ...); m_renderer.init(m_window);`
+// compiles and runs unedited.
+#if defined(GSX_FACADE_WITH_GLFW)
+#include <GLFW/glfw3.h>
+#else
+struct GLFWwindow { int width = 0, height = 0; };
+struct GLFWmonitor;
+inline GLFWwindow* glfwCreateWindow(int width, int height, const char* /*title*/, GLFWmonitor* /*monitor*/, GLFWwindow* /*share*/) {
+    GLFWwindow* w = new GLFWwindow;
+    w->width = width;
+    w->height = height;
+    return w;
+}
+inline void glfwGetWindowSize(GLFWwindow* window, int* width, int* height) {
+    if (width) *width = window ? window->width : 0;
+    if (height) *height = window ? window->height : 0;
+}
+inline void glfwDestroyWindow(GLFWwindow* window) { delete window; }
+#endif
 
 namespace gsx {
 namespace wgpu {
@@ -71,13 +96,19 @@ struct Device {
     }
     explicit operator bool() const { return static_cast<bool>(ctx); }
     void release() { ctx.reset(); }
+    void poll(bool /*wait*/) const {}      // main.cpp:288 (wgpu-native); gsx calls complete on their own stream
+    void tick() const {}                   // main.cpp:286 (Dawn)
 };
+struct CommandBuffer { void release() {} };
+struct CommandBufferDescriptor { const char* label = nullptr; };
+struct CommandEncoderDescriptor { const char* label = nullptr; };
 struct Queue {
     std::shared_ptr<gsx_ctx> ctx;
     void writeBuffer(Buffer& b, uint64_t offset, const void* data, uint64_t size) const {
         if (!b.host || offset + size > b.host->size()) throw std::out_of_range("writeBuffer outside the buffer");
         std::memcpy(b.host->data() + offset, data, size);
     }
+    void submit(uint32_t /*count*/, const CommandBuffer* /*commands*/) const {}   // main.cpp:275: render() already ran the frame
     explicit operator bool() const { return static_cast<bool>(ctx); }
     void release() { ctx.reset(); }
 };
@@ -88,8 +119,25 @@ struct TextureView {
     explicit operator bool() const { return static_cast<bool>(pixels); }
     void release() { pixels.reset(); }
 };
-struct CommandEncoder {};
+struct CommandEncoder {
+    CommandBuffer finish(const CommandBufferDescriptor&) { return CommandBuffer{}; }   // main.cpp:271
+    void release() {}
+};
+inline CommandEncoder wgpuDeviceCreateCommandEncoder(const Device&, const CommandEncoderDescriptor*) { return CommandEncoder{}; }   // main.cpp:249-250
 struct RenderPipeline { void release() {} };
+enum class ErrorType { NoError, Validation, OutOfMemory, Internal, Unknown, DeviceLost };
+using ErrorCallback = std::function<void(ErrorType, const char*)>;   // webgpu.hpp's ErrorCallback
+// The swap chain of renderer.cpp:73-95,123-151: one RGBA8 frame in host memory that render() fills by readback.
+// present() hands it to `onPresent` (the optional viewer front end blits it); headless it is a no-op.
+struct Surface {
+    std::shared_ptr<std::vector<uint8_t>> frame;
+    uint32_t width = 0, height = 0;
+    std::function<void(const uint8_t* rgba8, uint32_t width, uint32_t height)> onPresent;
+    void present() const { if (onPresent && frame) onPresent(frame->data(), width, height); }   // main.cpp:282
+    void unconfigure() {}
+    void release() { frame.reset(); }
+    explicit operator bool() const { return static_cast<bool>(frame); }
+};
 struct RenderPassEncoder {
     TextureView target;
     BindGroup bindGroup;
@@ -130,35 +178,51 @@ struct GUI {
     } params;
 };
 
-// renderer.hpp:10-35.  init() takes the frame size and GPU ordinal instead of a GLFW window
-// (windowing is out of scope); everything after init() has the reference's shape.
+// renderer.hpp:10-35: same public members and methods.  `gpu` (the HIP device ordinal, set before init) is the one
+// addition; init(width, height, gpu) without a window is kept as an extra for headless callers.
 class Renderer {
 public:
-    int width = 0, height = 0;
+    GLFWwindow* window = nullptr;
+    int width = 0;
+    int height = 0;
+
     Device device;
     Queue queue;
+    Surface surface;
     TextureFormat surface_format = TextureFormat::Undefined;
     RenderPipeline pipeline;
 
+    std::unique_ptr<ErrorCallback> uncaptured_error_callback_handle;
+
+    int gpu = 0;
+
+public:
     Renderer() = default;
-    ~Renderer() { queue.release(); device.release(); }
-    void init(int frame_width, int frame_height, int gpu = 0) {   // renderer.cpp:3-100
+    ~Renderer() {                                                 // renderer.cpp:178-183
+        surface.unconfigure();
+        queue.release();
+        surface.release();
+        device.release();
+    }
+
+    void init(GLFWwindow* window) {                               // renderer.cpp:3-100
+        this->window = window;
+        glfwGetWindowSize(window, &width, &height);
+        bring_up();
+    }
+    void init(int frame_width, int frame_height, int gpu_ordinal = 0) {
+        window = nullptr;
         width = frame_width;
         height = frame_height;
-        gsx_ctx* raw = nullptr;
-        const int rc = gsx_create(gpu, &raw);
-        if (rc != GSX_OK) throw std::runtime_error("Failed to get a gsx device (" + std::to_string(rc) + ")");
-        device.ctx = std::shared_ptr<gsx_ctx>(raw, [](gsx_ctx* c) { gsx_destroy(c); });
-        queue.ctx = device.ctx;
-        surface_format = TextureFormat::RGBA8Unorm;
-        frame = std::make_shared<std::vector<uint8_t>>(static_cast<size_t>(width) * height * 4);
+        gpu = gpu_ordinal;
+        bring_up();
     }
     TextureView get_next_surface_texture_view() {                 // renderer.cpp:123-151
         TextureView v;
-        if (!frame) return v;
-        v.width = static_cast<uint32_t>(width);
-        v.height = static_cast<uint32_t>(height);
-        v.pixels = frame;
+        if (!surface) return v;                                   // (the reference returns nullptr when the surface has no texture)
+        v.width = surface.width;
+        v.height = surface.height;
+        v.pixels = surface.frame;
         return v;
     }
     RenderPassEncoder create_render_pass_encoder(TextureView& targetView, CommandEncoder&) {  // renderer.cpp:153-176
@@ -168,7 +232,31 @@ public:
     }
 
 private:
-    std::shared_ptr<std::vector<uint8_t>> frame;
+    // Like the reference, a failed bring-up prints and returns (renderer.cpp:12-15,23-26,51-54): `device` stays null and the
+    // first SplatMesh call on it throws.
+    void bring_up() {
+        if (width <= 0 || height <= 0) {
+            std::cerr << "Failed to create a surface: window size " << width << " x " << height << "." << std::endl;
+            return;
+        }
+        gsx_ctx* raw = nullptr;
+        const int rc = gsx_create(gpu, &raw);
+        if (rc != GSX_OK) {
+            std::cerr << "Failed to get a gsx device on GPU " << gpu << " (" << rc << ")." << std::endl;
+            return;
+        }
+        device.ctx = std::shared_ptr<gsx_ctx>(raw, [](gsx_ctx* c) { gsx_destroy(c); });
+        uncaptured_error_callback_handle = std::make_unique<ErrorCallback>([](ErrorType type, const char* message) {   // renderer.cpp:58-63
+            std::cout << "Uncaptured device error: type " << static_cast<int>(type);
+            if (message) std::cout << " (" << message << ")";
+            std::cout << std::endl;
+        });
+        queue.ctx = device.ctx;
+        surface_format = TextureFormat::RGBA8Unorm;
+        surface.width = static_cast<uint32_t>(width);
+        surface.height = static_cast<uint32_t>(height);
+        surface.frame = std::make_shared<std::vector<uint8_t>>(static_cast<size_t>(width) * height * 4);
+    }
 };
 
 class SplatMesh {
@@ -236,6 +324,7 @@ public:
         ensureUploaded();
         gsx_check(ctx(), gsx_select_list(ctx(), idx.data(), static_cast<uint32_t>(idx.size())), "gsx_select_list");
         selectionIsAll = false;
+        cutValid = false;         // the device selection is now `idx`: a cached LOD cut must be re-selected by the next render()
         const float cam[3] = {cameraPos.x, cameraPos.y, cameraPos.z};
         std::vector<uint32_t> out(std::max<size_t>(idx.size(), 1));
         gsx_check(ctx(), gsx_sort(ctx(), cam, out.data()), "gsx_sort");
@@ -286,6 +375,10 @@ protected:
 
     bool uploaded = false;
     bool selectionIsAll = false;
+    // HC / GridHC: the view-independent depth cut currently held by the device selection (cleared by anything else
+    // that replaces the selection, e.g. the public sortSplats)
+    bool cutValid = false;
+    uint32_t cutDepth = 0;
 
 private:
     void initializeBuffers() {                                     // SplatMesh.h:125-185
@@ -383,8 +476,6 @@ protected:
         gsx_check(ctx(), gsx_set_lod_hc(ctx(), &t), "gsx_set_lod_hc");
         cutValid = false;
     }
-    bool cutValid = false;
-    uint32_t cutDepth = 0;
 };
 
 class SplatMeshGridHC : public SplatMesh {
@@ -433,8 +524,6 @@ protected:
         gsx_check(ctx(), gsx_set_lod_hc(ctx(), &t), "gsx_set_lod_hc");
         cutValid = false;
     }
-    bool cutValid = false;
-    uint32_t cutDepth = 0;
 };
 
 }  // namespace gsx

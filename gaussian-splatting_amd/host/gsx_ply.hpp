@@ -113,6 +113,15 @@ inline PlyStatus load_ply_raw(const std::string& path, std::vector<SplatRaw>& ou
             if (p.name == need[k]) { src[k] = &p; break; }
         if (!src[k]) return PlyStatus::MissingProperty;
     }
+    {   // the vertex count comes from an untrusted header: it must fit the bytes that are actually left in the file
+        const std::streamoff here = f.tellg();
+        f.seekg(0, std::ios::end);
+        const std::streamoff end = f.tellg();
+        f.seekg(here, std::ios::beg);
+        if (here < 0 || end < here || !f) return PlyStatus::BadHeader;
+        const uint64_t left = static_cast<uint64_t>(end - here);
+        if (stride <= 0 || n > left / static_cast<uint64_t>(stride)) return PlyStatus::Truncated;
+    }
     out.resize(n);
     const uint64_t chunk = 1u << 16;
     std::vector<unsigned char> buf(static_cast<size_t>(chunk) * stride);

@@ -29,8 +29,12 @@ static void dump(const std::string& path, const T* data, size_t count) {
 
 template <typename Mesh>
 static void run(const char* name, const std::string& scene_path, const std::string& out, int w, int h, GUI& gui, int orbit_steps) {
+    GLFWwindow* window = glfwCreateWindow(w, h, "Gaussian Splatting", nullptr, nullptr);   // main.cpp:162-163
     Renderer renderer;
-    renderer.init(w, h);
+    renderer.init(window);                                         // main.cpp:188, the reference's signature
+    if (renderer.window != window || renderer.width != w || renderer.height != h || !renderer.device || !renderer.queue ||
+        !renderer.surface || !renderer.uncaptured_error_callback_handle)
+        throw std::runtime_error("Renderer::init(GLFWwindow*) did not fill the reference's public members");
     Mesh splatMesh;
     splatMesh.loadData(scene_path, true);                          // main.cpp:428
     splatMesh.initialize(renderer.device, renderer.queue);         // main.cpp:431
@@ -64,13 +68,25 @@ static void run(const char* name, const std::string& scene_path, const std::stri
         uniforms.bayerSize = gui.params.bayerSize;
         uniforms.bayerScale = gui.params.bayerScale;
         renderer.queue.writeBuffer(transformBuffer, 0, &uniforms, sizeof(Uniforms));   // main.cpp:239-240
-        TextureView targetView = renderer.get_next_surface_texture_view();
-        CommandEncoder encoder;
+        TextureView targetView = renderer.get_next_surface_texture_view();   // main.cpp:243-253
+        if (!targetView) throw std::runtime_error("no surface texture view");
+        CommandEncoderDescriptor encoderDesc = {};
+        encoderDesc.label = "My command encoder";
+        CommandEncoder encoder = wgpuDeviceCreateCommandEncoder(renderer.device, &encoderDesc);
         RenderPassEncoder renderPass = renderer.create_render_pass_encoder(targetView, encoder);
         renderPass.setPipeline(renderer.pipeline);
         renderPass.setBindGroup(0, bindGroup, 0, nullptr);
         splatMesh.render(renderPass, camera, gui.params);          // main.cpp:261
         renderPass.end();
+        renderPass.release();                                      // main.cpp:265-289, unedited
+        CommandBufferDescriptor cmdBufferDescriptor = {};
+        cmdBufferDescriptor.label = "Command buffer";
+        CommandBuffer command = encoder.finish(cmdBufferDescriptor);
+        encoder.release();
+        renderer.queue.submit(1, &command);
+        command.release();
+        renderer.surface.present();
+        renderer.device.poll(false);
         if (frame == 1) {
             const std::string p = out + "/" + name;
             dump(p + ".splats", splatMesh.splatData.data(), splatMesh.splatData.size());
@@ -81,7 +97,9 @@ static void run(const char* name, const std::string& scene_path, const std::stri
             std::printf("%s n=%zu drawn=%u indices=%zu\n", name, splatMesh.splatData.size(), renderPass.drawnInstances,
                         splatMesh.indices.size());
         }
+        targetView.release();                                      // main.cpp:280
     }
+    glfwDestroyWindow(window);                                     // main.cpp:205
 }
 
 int main(int argc, char** argv) {

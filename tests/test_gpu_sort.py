@@ -1,4 +1,4 @@
-"""GPU parity: upload, depth keys, the onesweep sort and the LOD cuts, called through
+"""GPU parity: upload, depth keys, the stable LSD radix sort and the LOD cuts, called through
 the C ABI (libgsx.so) and compared bit for bit with the CPU oracle / golden fixtures."""
 import numpy as np
 import pytest
@@ -204,6 +204,68 @@ def test_gridhc_depth_cut_through_select_list(gsx, oracle):
         ref_cut = g[f"g_cut_depth_{d}"]
         gsx.select_list(ref_cut)
         assert np.array_equal(gsx.sort(cam), oracle.sort_contract(g["g_splats"], cam, np.sort(ref_cut)))
+
+
+def test_error_flags_are_reported_once(gsx_fresh, pkg, oracle, synth):
+    """A bad selection list (id >= n) or a non-finite position is reported by the call that meets it and by no later one:
+    the device error words are cleared once read, so the context keeps working (they used to be sticky)."""
+    gsx = gsx_fresh
+    n, w, h = 5000, 96, 64
+    splats = oracle.raw_to_splat(synth.uniform_cloud(n, seed=3))
+    gsx.upload(splats)
+    cam = CAMS[0]
+    bad = np.array([1, 2, n + 5, 7], np.uint32)
+    with pytest.raises(pkg.GsxError) as e:
+        gsx.select_list(bad)
+    assert e.value.code == pkg.GSX_E_INVALID
+    good = np.arange(0, n, 2, dtype=np.uint32)
+    gsx.select_list(good)                                             # a valid list right after: no stale error
+    perm = gsx.sort(cam)
+    assert np.array_equal(perm, oracle.sort_contract(splats, cam, good))
+    world, _ = oracle.orbit_world(5.0, (0.0, 1.0, 0.0), 0.0, 0)
+    view, proj, vp, campos = oracle.camera(world, 45.0, w / h)
+    img = gsx.render(pkg.make_uniforms(proj, view), w, h)
+    assert img[..., :3].std() > 1
+    gsx.sync()
+    # a NaN position leaves the host's distance bound: the sort that meets it reports GSX_E_INTERNAL, the next upload is clean
+    broken = splats.copy()
+    broken[17, 12] = np.nan
+    gsx.upload(broken)
+    with pytest.raises(pkg.GsxError) as e:
+        gsx.sort(cam)
+    assert e.value.code == pkg.GSX_E_INTERNAL
+    gsx.select_list(good)                                             # no stale key_bound error on an unrelated call
+    gsx.upload(splats)
+    assert np.array_equal(gsx.sort(cam), oracle.sort_contract(splats, cam))
+
+
+def test_hc_forest_with_a_cycle_is_rejected(gsx_fresh, pkg, oracle, synth):
+    gsx = gsx_fresh
+    n = 64
+    gsx.upload(oracle.raw_to_splat(synth.uniform_cloud(n, seed=2)))
+    parent = np.full(n, 0xFFFFFFFF, np.uint32)
+    parent[:10] = np.arange(1, 11)            # a chain 0 -> 1 -> ... -> 10 (root): fine
+    leaf = np.ones(n, np.uint8)
+    gsx.set_lod_hc(parent, leaf, np.ones(n, np.float32), np.ones(n, np.float32))
+    parent[10] = 3                            # 3 -> 4 -> ... -> 10 -> 3
+    with pytest.raises(pkg.GsxError) as e:
+        gsx.set_lod_hc(parent, leaf, np.ones(n, np.float32), np.ones(n, np.float32))
+    assert e.value.code == pkg.GSX_E_INVALID
+    parent[:] = 0xFFFFFFFF
+    parent[5] = 5                             # self loop
+    with pytest.raises(pkg.GsxError):
+        gsx.set_lod_hc(parent, leaf, np.ones(n, np.float32), np.ones(n, np.float32))
+
+
+def test_cfg1_full_size_bit_exact(gsx, oracle, synth):
+    """BASELINE.json configs[0] at its full size: 1M-splat uniform cloud, default OrbitCamera(5) pose, keys + sort,
+    byte for byte against the oracle's contract order."""
+    n = 1_000_000
+    splats = oracle.raw_to_splat(synth.uniform_cloud(n, seed=1))
+    gsx.upload(splats)
+    cam = np.array([0.0, 0.0, 5.0], np.float32)
+    assert np.array_equal(bits(gsx.keys(cam)), bits(oracle.distance_keys(splats, cam)))
+    assert np.array_equal(gsx.sort(cam), oracle.sort_contract(splats, cam))
 
 
 def test_upload_rejects_asymmetric_covariance(gsx, pkg):

@@ -162,3 +162,12 @@ def test_ply_reader(pkg, oracle, tmp_path):
     with pytest.raises(pkg.GsxError) as e:
         scene.load_ply_raw(pkg, tmp_path / "noprop.ply")
     assert e.value.code == pkg.GSX_E_INVALID
+    # a header that claims far more vertices than the file holds: an error code, no exception across the C ABI,
+    # no multi-gigabyte allocation
+    head, _, body = data.partition(b"end_header\n")
+    import re
+    huge = re.sub(rb"element vertex \d+", b"element vertex 1152921504606846976", head) + b"end_header\n" + body
+    (tmp_path / "huge.ply").write_bytes(huge)
+    with pytest.raises(pkg.GsxError) as e:
+        scene.load_ply_raw(pkg, tmp_path / "huge.ply")
+    assert e.value.code == pkg.GSX_E_INVALID
