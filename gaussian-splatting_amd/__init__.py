@@ -22,7 +22,7 @@ GSX_OK, GSX_E_INVALID, GSX_E_HIP, GSX_E_NOMEM, GSX_E_STATE, GSX_E_UNSUPPORTED, G
 ABI_SYMBOLS = [
     "gsx_create", "gsx_destroy", "gsx_last_error", "gsx_sync", "gsx_set_profiling", "gsx_get_timings", "gsx_get_scatter_samples", "gsx_set_option",
     "gsx_upload_splats", "gsx_upload_splats_dev", "gsx_select_all", "gsx_select_list", "gsx_set_lod_octree",
-    "gsx_set_lod_hc", "gsx_select_octree", "gsx_select_hc", "gsx_get_selection", "gsx_sort", "gsx_get_sorted_dev",
+    "gsx_set_lod_hc", "gsx_select_octree", "gsx_select_hc", "gsx_get_selection", "gsx_sort", "gsx_sort_noalloc", "gsx_get_sorted_dev",
     "gsx_get_keys", "gsx_render", "gsx_get_framebuffer_dev", "gsx_set_framebuffer_dev", "gsx_get_stream",
     "gsx_host_convert_raw", "gsx_host_load_splat_file", "gsx_host_free", "gsx_host_load_ply_raw", "gsx_host_load_ply_file", "gsx_host_camera", "gsx_host_orbit_pose",
     "gsx_host_octree_build", "gsx_host_hc_build", "gsx_host_gridhc_build", "gsx_host_lod_free", "gsx_host_lod_size",
@@ -177,6 +177,11 @@ class Gsx:
         m = C.c_uint32(0)
         self._chk(self.lib.gsx_get_sorted_dev(self.ctx, C.byref(dev), C.byref(m)))
         return out[:m.value].copy()
+
+    def sort_noalloc(self, cam_pos, out_dev_ptr, capacity):
+        """gsx_sort_noalloc: queue the sort of the current selection into caller-owned device memory (no allocation, no wait)."""
+        cam = np.ascontiguousarray(cam_pos, np.float32)
+        self._chk(self.lib.gsx_sort_noalloc(self.ctx, _ptr(cam), C.c_void_p(out_dev_ptr), C.c_uint32(int(capacity))))
 
     def sorted_dev(self):
         dev = C.c_void_p()

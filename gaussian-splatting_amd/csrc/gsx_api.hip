@@ -87,6 +87,7 @@ int gsx_create(int device, gsx_ctx** out) {
     auto fail = [&](int rc) { gsx_destroy(c); return rc; };
     if (hipSetDevice(device) != hipSuccess) return fail(GSX_E_HIP);
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return fail(GSX_E_HIP);
+    if (gsx_scratch_init(c, device) != GSX_OK) return fail(GSX_E_HIP);
     {
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus < 1) cus = 256;
@@ -445,6 +446,19 @@ int gsx_sort(gsx_ctx* c, const float cam_pos[3], uint32_t* idx_out_host) {
         if (m) GSX_HIP(c, hipMemcpy(idx_out_host, c->perm[c->perm_cur], static_cast<uint64_t>(m) * 4, hipMemcpyDeviceToHost));
     }
     return GSX_OK;
+}
+
+int gsx_sort_noalloc(gsx_ctx* c, const float cam_pos[3], uint32_t* idx_out_dev, uint32_t capacity) {
+    if (!c || !cam_pos || !idx_out_dev) return GSX_E_INVALID;
+    if (c->n == 0 && c->m_cap == 0) return GSX_OK;
+    if (capacity < c->m_cap) { c->err = "gsx_sort_noalloc: output buffer smaller than the selection"; return GSX_E_INVALID; }
+    int rc = set_device(c);
+    if (rc) return rc;
+    const float keep[3] = {c->cam[0], c->cam[1], c->cam[2]};   // (the frame loop's schedule looks at the camera of the context's own sorts)
+    c->cam[0] = cam_pos[0]; c->cam[1] = cam_pos[1]; c->cam[2] = cam_pos[2];
+    rc = gsx_launch_sort_noalloc(c, idx_out_dev);     // queued on the context's stream; no allocation, no readback, no wait
+    c->cam[0] = keep[0]; c->cam[1] = keep[1]; c->cam[2] = keep[2];
+    return rc;
 }
 
 int gsx_get_sorted_dev(gsx_ctx* c, const uint32_t** idx_dev, uint32_t* m) {

@@ -20,6 +20,7 @@
 #define GSX_SORT_IPT 12
 #endif
 #define GSX_SORT_TILE (GSX_SORT_NT * GSX_SORT_IPT)
+#define GSX_NOALLOC_MAX_KEYS GSX_SORT_NOALLOC_MAX   // gsx_sort_noalloc: largest selection its 20 MiB scratch array holds
 #define GSX_PAIR_NT 512
 #define GSX_PAIR_IPT 12
 #define GSX_PAIR_TILE (GSX_PAIR_NT * GSX_PAIR_IPT)
@@ -249,6 +250,8 @@ static inline uint32_t gsx_div_up(uint64_t a, uint64_t b) { return static_cast<u
 // ---- launchers (defined in the .hip files) ----
 int gsx_launch_upload(gsx_ctx* c, const void* aos80_dev, uint64_t n);
 int gsx_launch_sort(gsx_ctx* c);                 // keygen + plan + radix passes on the current selection
+int gsx_scratch_init(gsx_ctx* c, int device);    // looks up the per-device address of the no-alloc scratch array (gsx_create)
+int gsx_launch_sort_noalloc(gsx_ctx* c, uint32_t* idx_out_dev);   // the same sort inside the file-scope scratch array
 int gsx_launch_keys_only(gsx_ctx* c, float* dist_dev);
 int gsx_launch_select_octree(gsx_ctx* c, const float vp[16], float thr);
 int gsx_launch_select_hc(gsx_ctx* c, const float cam[3], float thr);

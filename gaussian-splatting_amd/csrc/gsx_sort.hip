@@ -216,11 +216,23 @@ static void launch_pass(gsx_ctx* c, hipStream_t st, uint32_t g, const KeyT* kin,
     if (ev1) (void)hipEventRecord(ev1, st);
 }
 
-int gsx_launch_sort(gsx_ctx* c) {
+// The buffers one depth sort works in: key / value ping-pong arrays, the radix count matrix, and where the
+// permutation goes.  gsx_sort uses the context's own arrays; gsx_sort_noalloc carves them out of `scratch` below.
+struct GsxSortBuffers {
+    uint32_t* keys[2];
+    uint32_t* vals[2];
+    uint32_t* ws;
+    uint64_t ws_words;
+    uint32_t* result;
+    bool with_events;      // profiling events / sampled scatter launches (the context's own sort only)
+};
+
+static int launch_sort_in(gsx_ctx* c, const GsxSortBuffers& sb) {
     const uint32_t cap = c->m_cap;
     const uint32_t g = gsx_radix_blocks(cap, GSX_SORT_TILE, c->sort_slots);
     const uint32_t cols = gsx_radix_columns(c->sort_slots);
-    if (gsx_radix_workspace_words(cols) > c->sort_ws_words) { c->err = "sort workspace too small"; return GSX_E_INTERNAL; }
+    if (gsx_radix_workspace_words(cols) > sb.ws_words) { c->err = "sort workspace too small"; return GSX_E_INTERNAL; }
+    const bool profiling = c->profiling && sb.with_events;
     uint32_t key_lo, key_span;
     key_bounds(c, &key_lo, &key_span);
     uint32_t total_bits = 0;
@@ -234,53 +246,122 @@ int gsx_launch_sort(gsx_ctx* c) {
     const GsxRadixPlan plan = gsx_radix_plan(top_bits ? LOW_BITS : total_bits);
     const uint32_t wide_mask = top_bits ? ~((1u << LOW_BITS) - 1u) : 0u;
     if (top_bits) GSX_HIP(c, hipMemsetAsync(&c->flags->wide_m, 0, sizeof(uint32_t), c->stream));
-    if (c->profiling) GSX_HIP(c, hipEventRecord(c->ev[EV_KEY0], c->stream));
+    if (profiling) GSX_HIP(c, hipEventRecord(c->ev[EV_KEY0], c->stream));
     if (c->sel_iota)
         hipLaunchKernelGGL(k_keygen_hist0<true>, dim3(g), dim3(GSX_SORT_NT), 0, c->stream, c->pos4, nullptr, c->m_dev, c->cam[0],
-                           c->cam[1], c->cam[2], key_lo, key_span, plan.shift[0], plan.bits[0], wide_mask, c->keys[0], c->sort_ws, cols,
+                           c->cam[1], c->cam[2], key_lo, key_span, plan.shift[0], plan.bits[0], wide_mask, sb.keys[0], sb.ws, cols,
                            c->flags);
     else
         hipLaunchKernelGGL(k_keygen_hist0<false>, dim3(g), dim3(GSX_SORT_NT), 0, c->stream, c->pos4, c->sel_idx, c->m_dev, c->cam[0],
-                           c->cam[1], c->cam[2], key_lo, key_span, plan.shift[0], plan.bits[0], wide_mask, c->keys[0], c->sort_ws, cols,
+                           c->cam[1], c->cam[2], key_lo, key_span, plan.shift[0], plan.bits[0], wide_mask, sb.keys[0], sb.ws, cols,
                            c->flags);
-    if (c->profiling) GSX_HIP(c, hipEventRecord(c->ev[EV_KEY1], c->stream));
+    if (profiling) GSX_HIP(c, hipEventRecord(c->ev[EV_KEY1], c->stream));
     uint32_t cur = 0;
-    c->sampled_pass = (c->prof_level == 2 && plan.n_passes > 0) ? static_cast<int>(c->prof_frame % static_cast<uint32_t>(plan.n_passes)) : -1;
-    ++c->prof_frame;
+    int sampled_pass = -1;
+    if (sb.with_events) {
+        sampled_pass = c->sampled_pass = (c->prof_level == 2 && plan.n_passes > 0) ? static_cast<int>(c->prof_frame % static_cast<uint32_t>(plan.n_passes)) : -1;
+        ++c->prof_frame;
+    }
     hipEvent_t samp0 = nullptr, samp1 = nullptr;
-    if (c->sampled_pass >= 0) {
+    if (sampled_pass >= 0) {
         const uint32_t slot = c->samp_pos++ % GSX_SAMPLE_RING;
         gsx_sample_drain(c, slot);                  // (a slot comes round again 32 frames later: long finished)
-        c->samp_pass[slot] = c->sampled_pass;
+        c->samp_pass[slot] = sampled_pass;
         samp0 = c->samp_ev[slot][0];
         samp1 = c->samp_ev[slot][1];
     }
-    uint32_t* result = c->perm[c->perm_cur ^ 1u];
+    uint32_t* result = sb.result;
     for (int p = 0; p < plan.n_passes; ++p) {
         const bool first = p == 0, last = p + 1 == plan.n_passes;
-        hipEvent_t e0 = c->profiling ? c->ev[EV_X0 + 2 * p] : (c->sampled_pass == p ? samp0 : nullptr);
-        hipEvent_t e1 = c->profiling ? c->ev[EV_X0 + 2 * p + 1] : (c->sampled_pass == p ? samp1 : nullptr);
-        launch_pass<uint32_t, GSX_SORT_NT, GSX_SORT_IPT>(c, c->stream, g, c->keys[cur], first ? c->sel_idx : c->vals[cur], c->keys[cur ^ 1],
-                                                          last ? result : c->vals[cur ^ 1], c->m_dev, plan.shift[p], plan.bits[p], c->sort_ws,
+        hipEvent_t e0 = profiling ? c->ev[EV_X0 + 2 * p] : (sampled_pass == p ? samp0 : nullptr);
+        hipEvent_t e1 = profiling ? c->ev[EV_X0 + 2 * p + 1] : (sampled_pass == p ? samp1 : nullptr);
+        launch_pass<uint32_t, GSX_SORT_NT, GSX_SORT_IPT>(c, c->stream, g, sb.keys[cur], first ? c->sel_idx : sb.vals[cur], sb.keys[cur ^ 1],
+                                                          last ? result : sb.vals[cur ^ 1], c->m_dev, plan.shift[p], plan.bits[p], sb.ws,
                                                           cols, /*need_hist=*/!first, /*iota=*/first && c->sel_iota, e0, e1);
         cur ^= 1;
     }
     if (top_bits) {   // gated top digit: result -> scratch values, then back (all four kernels see count 0 in the common case)
         static_assert(EV_X0 + 2 * 3 + 1 < EV_X_END, "event slots of the gated pass");
-        launch_pass<uint32_t, GSX_SORT_NT, GSX_SORT_IPT>(c, c->stream, g, c->keys[cur], result, c->keys[cur ^ 1], c->vals[cur ^ 1],
-                                                          &c->flags->wide_m, LOW_BITS, top_bits, c->sort_ws, cols, /*need_hist=*/true,
-                                                          /*iota=*/false, c->profiling ? c->ev[EV_X0 + 6] : nullptr,
-                                                          c->profiling ? c->ev[EV_X0 + 7] : nullptr);
-        hipLaunchKernelGGL(k_copy_gated, dim3(g), dim3(512), 0, c->stream, &c->flags->wide_m, c->vals[cur ^ 1], result);
+        launch_pass<uint32_t, GSX_SORT_NT, GSX_SORT_IPT>(c, c->stream, g, sb.keys[cur], result, sb.keys[cur ^ 1], sb.vals[cur ^ 1],
+                                                          &c->flags->wide_m, LOW_BITS, top_bits, sb.ws, cols, /*need_hist=*/true,
+                                                          /*iota=*/false, profiling ? c->ev[EV_X0 + 6] : nullptr,
+                                                          profiling ? c->ev[EV_X0 + 7] : nullptr);
+        hipLaunchKernelGGL(k_copy_gated, dim3(g), dim3(512), 0, c->stream, &c->flags->wide_m, sb.vals[cur ^ 1], result);
     }
-    c->perm_cur ^= 1u;
-    if (c->profiling) GSX_HIP(c, hipEventRecord(c->ev[EV_SORT1], c->stream));
+    if (profiling) GSX_HIP(c, hipEventRecord(c->ev[EV_SORT1], c->stream));
     GSX_HIP(c, hipGetLastError());
-    c->sorted_valid = true;
-    c->sort_passes = static_cast<uint32_t>(plan.n_passes) + (top_bits ? 1u : 0u);   // (the gated pass counts as launched)
-    c->sort_gated = top_bits != 0;
+    if (sb.with_events) {   // (the context's own sort: what gsx_get_timings reports)
+        c->sort_passes = static_cast<uint32_t>(plan.n_passes) + (top_bits ? 1u : 0u);   // (the gated pass counts as launched)
+        c->sort_gated = top_bits != 0;
+    }
     return GSX_OK;
 }
+
+int gsx_launch_sort(gsx_ctx* c) {
+    GsxSortBuffers sb;
+    sb.keys[0] = c->keys[0]; sb.keys[1] = c->keys[1];
+    sb.vals[0] = c->vals[0]; sb.vals[1] = c->vals[1];
+    sb.ws = c->sort_ws;
+    sb.ws_words = c->sort_ws_words;
+    sb.result = c->perm[c->perm_cur ^ 1u];
+    sb.with_events = true;
+    const int rc = launch_sort_in(c, sb);
+    if (rc != GSX_OK) return rc;
+    c->perm_cur ^= 1u;
+    c->sorted_valid = true;
+    return GSX_OK;
+}
+
+// ---------------------------------------------------------------------------
+// gsx_sort_noalloc: the depth sort for callers that cannot allocate (HIP graph capture, serving loops).
+// Its key / value ping-pong arrays and the radix count matrix live in `scratch`, a file-scope device array
+// that every GPU the library runs on holds until the process ends.  In host code the array's NAME is only
+// a stand-in: its device address is looked up per device with hipGetSymbolAddress at gsx_create time
+// (gsx_scratch_init) and only that pointer is ever handed to kernels.
+// ---------------------------------------------------------------------------
+#define GSX_NOALLOC_WS_WORDS (static_cast<uint64_t>(GSX_RADIX_MAX_DIGITS) * GSX_RADIX_MAX_BLOCKS + GSX_RADIX_MAX_DIGITS)
+#define GSX_NOALLOC_SCRATCH_BYTES (4ull * GSX_NOALLOC_MAX_KEYS * sizeof(uint32_t) + GSX_NOALLOC_WS_WORDS * sizeof(uint32_t))
+static __device__ __align__(256) unsigned char scratch[GSX_NOALLOC_SCRATCH_BYTES];
+
+#define GSX_MAX_DEVICES 64
+static unsigned char* g_scratch_ptr[GSX_MAX_DEVICES] = {};   // per device: each GPU holds its own copy at its own address
+
+// Called by gsx_create with `device` current.
+int gsx_scratch_init(gsx_ctx* c, int device) {
+    if (device < 0 || device >= GSX_MAX_DEVICES) return GSX_OK;   // (gsx_sort_noalloc reports it)
+    if (g_scratch_ptr[device]) return GSX_OK;
+    void* p = nullptr;
+    GSX_HIP(c, hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+    g_scratch_ptr[device] = static_cast<unsigned char*>(p);
+    return GSX_OK;
+}
+
+int gsx_launch_sort_noalloc(gsx_ctx* c, uint32_t* idx_out_dev) {
+    if (c->device < 0 || c->device >= GSX_MAX_DEVICES || !g_scratch_ptr[c->device]) {
+        c->err = "gsx_sort_noalloc: no scratch address for this device";
+        return GSX_E_STATE;
+    }
+    if (c->m_cap > GSX_NOALLOC_MAX_KEYS) {
+        c->err = "gsx_sort_noalloc: selection of " + std::to_string(c->m_cap) + " splats exceeds the scratch array's " +
+                 std::to_string(GSX_NOALLOC_MAX_KEYS) + " (use gsx_sort)";
+        return GSX_E_UNSUPPORTED;
+    }
+    uint32_t* base = reinterpret_cast<uint32_t*>(g_scratch_ptr[c->device]);
+    GsxSortBuffers sb;
+    sb.keys[0] = base;
+    sb.keys[1] = base + GSX_NOALLOC_MAX_KEYS;
+    sb.vals[0] = base + 2ull * GSX_NOALLOC_MAX_KEYS;
+    sb.vals[1] = base + 3ull * GSX_NOALLOC_MAX_KEYS;
+    sb.ws = base + 4ull * GSX_NOALLOC_MAX_KEYS;
+    sb.ws_words = GSX_NOALLOC_WS_WORDS;
+    sb.result = idx_out_dev;
+    sb.with_events = false;
+    // Nothing in the scratch has to start at zero: every count-matrix column a pass reads was written by the same
+    // pass's count kernel (their column count derives from the same device-side key count), and keys / values are
+    // written before they are read; what an earlier, larger call left behind is never looked at.
+    return launch_sort_in(c, sb);
+}
+
 
 int gsx_launch_keys_only(gsx_ctx* c, float* dist_dev) {
     if (c->m_cap == 0) return GSX_OK;

@@ -158,6 +158,19 @@ int gsx_get_selection(gsx_ctx* ctx, uint32_t* idx_out_host, uint32_t capacity, u
  * permutation buffer, so that frame keeps drawing its own order). ---- */
 int gsx_sort(gsx_ctx* ctx, const float cam_pos[3], uint32_t* idx_out_host);
 int gsx_get_sorted_dev(gsx_ctx* ctx, const uint32_t** idx_dev, uint32_t* m);
+/* gsx_sort for callers that cannot allocate device memory (code under HIP graph capture, tight serving loops, harnesses
+ * that forbid hipMalloc).  No counterpart in the reference.  Same keys, same order (distance descending, ties by
+ * ascending index) over the current selection, but the sort's scratch (key / value ping-pong arrays, radix count
+ * matrix) lives in a file-scope device array of the library instead of the context's buffers, and the permutation is
+ * written to caller-owned DEVICE memory idx_out_dev (capacity >= selection size, else GSX_E_INVALID).  The call only
+ * queues kernels on the context's stream: it calls no hipMalloc / hipFree, reads nothing back and does not wait; the
+ * context's own permutation (gsx_render, gsx_get_sorted_dev) is left untouched, and device-side error words are
+ * reported by the next gsx_sync as usual.
+ * Limit: selections of at most GSX_SORT_NOALLOC_MAX splats (the scratch array is 20 MiB per GPU, held until the process
+ * ends); larger -> GSX_E_UNSUPPORTED, use gsx_sort.  All contexts on one GPU share that GPU's array: calls that overlap
+ * on one GPU (two contexts / two host threads) race -- serialize them. */
+#define GSX_SORT_NOALLOC_MAX (1u << 20)
+int gsx_sort_noalloc(gsx_ctx* ctx, const float cam_pos[3], uint32_t* idx_out_dev, uint32_t capacity);
 /* Parity aid: the f32 distance key (SplatMesh.h:93) of every selected splat, in
  * selection order, computed by the same device function the sort uses. */
 int gsx_get_keys(gsx_ctx* ctx, const float cam_pos[3], float* dist_out_host, uint32_t capacity);
