@@ -28,10 +28,13 @@ int gsx_host_convert_raw(const void* raw32, uint64_t n, int center, void* aos80_
     } catch (const std::exception&) {      // e.g. std::length_error from an absurd element count: nothing crosses the C ABI
         return GSX_E_INVALID;
     }
-    for (uint64_t i = 0; i < n; ++i) split[i] = raw_to_split(raw[i]);
+    // per-record conversions are independent (and dominated by three powf per record): all host cores; the mean for
+    // centring is a sequential sum in record order, as in ResourceManager.cpp:52-62
+    const unsigned threads = lod_detail::host_threads();
+    lod_detail::parallel_for(n, 1 << 14, threads, [&](size_t i) { split[i] = raw_to_split(raw[i]); });
     if (center && n) center_splats(split);
     Splat* out = static_cast<Splat*>(aos80_out);
-    for (uint64_t i = 0; i < n; ++i) out[i] = split_to_splat(split[i]);
+    lod_detail::parallel_for(n, 1 << 14, threads, [&](size_t i) { out[i] = split_to_splat(split[i]); });
     return GSX_OK;
 }
 
@@ -148,11 +151,11 @@ int gsx_host_octree_build(const void* raw32, uint64_t n, int center, gsx_lod** o
     try {
         const SplatRaw* raw = static_cast<const SplatRaw*>(raw32);
         SplatSplitVector split(n);
-        for (uint64_t i = 0; i < n; ++i) split[i] = raw_to_split(raw[i]);
+        lod_detail::parallel_for(n, 1 << 14, lod_detail::host_threads(), [&](size_t i) { split[i] = raw_to_split(raw[i]); });
         if (center && n) center_splats(split);
         auto* l = new gsx_lod();
         l->kind = 1;
-        l->octree.build(split);      // SplatMeshOctree.hpp:72-76
+        l->octree.build(std::move(split));      // SplatMeshOctree.hpp:72-76
         l->octree.generate();
         l->oflat = l->octree.flatten();
         *out = l;

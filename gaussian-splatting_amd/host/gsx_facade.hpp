@@ -427,7 +427,7 @@ public:
     }
     void loadData(const std::string& path, bool center) override {  // SplatMeshOctree.hpp:57-79
         SplatSplitVector s = loadSplatsAny(path, center);   // .splat as the reference; .ply too (gsx_ply.hpp)
-        octree.build(s);
+        octree.build(std::move(s));
         octree.generate();
         splatData = octree.splats;
         uploaded = false;

@@ -171,3 +171,94 @@ def test_ply_reader(pkg, oracle, tmp_path):
     with pytest.raises(pkg.GsxError) as e:
         scene.load_ply_raw(pkg, tmp_path / "huge.ply")
     assert e.value.code == pkg.GSX_E_INVALID
+
+
+# ---- the flat-array builders against the LIVE reference (oracle/_ref, this container only) on inputs the fixtures
+# ---- do not hold: exact ties in the pair heap, duplicate positions, chains of single-child nodes, tiny scenes ----
+def _split_from(oracle, raw):
+    return oracle.raw_to_split(raw)
+
+
+def _lattice_raw(synth, n_side, seed):
+    """Splats on a regular lattice with only two distinct shapes / colours: many pair errors are exactly equal."""
+    raw = synth.uniform_cloud(n_side ** 3, seed=seed).copy()
+    g = np.stack(np.meshgrid(*[np.arange(n_side, dtype=np.float32)] * 3, indexing="ij"), -1).reshape(-1, 3) * np.float32(0.25) - np.float32(0.5)
+    raw[:, 0:12] = np.ascontiguousarray(g).view(np.uint8).reshape(-1, 12)
+    raw[:, 12:] = raw[0, 12:]
+    raw[1::2, 12:] = raw[1, 12:]
+    return raw
+
+
+@pytest.mark.parametrize("case", ["lattice", "duplicates", "chain", "one", "two"])
+def test_octree_build_matches_live_reference(pkg, oracle, reference, synth, case):
+    lod = _lodmod()
+    if case == "lattice":
+        raw = _lattice_raw(synth, 6, 3)
+    elif case == "duplicates":                      # identical positions can never be separated: max_depth leaves with several splats
+        raw = synth.uniform_cloud(400, seed=4).copy()
+        raw[100:200, 0:12] = raw[100, 0:12]
+    elif case == "chain":                           # two tight groups far apart: long single-child chains that must fold
+        raw = synth.uniform_cloud(64, seed=5).copy()
+        pos = raw[:, 0:12].copy().view(np.float32).reshape(-1, 3)
+        pos[:32] = pos[:32] * np.float32(1e-3) + np.float32(2.9)
+        pos[32:] = pos[32:] * np.float32(1e-3) - np.float32(2.9)
+        raw[:, 0:12] = pos.view(np.uint8).reshape(-1, 12)
+    else:
+        raw = synth.uniform_cloud({"one": 1, "two": 2}[case], seed=6)
+    split = _split_from(oracle, raw)
+    ref = reference.octree_build(split)
+    t = lod.build_octree(raw, center=False)
+    assert t.n == len(ref["splats"])
+    assert np.array_equal(bits(t.splats), bits(ref["splats"]))
+    assert np.array_equal(bits(t.center3), bits(ref["center3"])) and np.array_equal(bits(t.half3), bits(ref["half3"]))
+    assert np.array_equal(t.first_child, ref["first_child"]) and np.array_equal(t.n_children, ref["n_children"])
+    world = np.eye(4, dtype=np.float32).reshape(-1).copy()
+    world[12:15] = [0.3, -0.2, 4.0]
+    for thr in (0.5, 0.02, 0.0005):
+        assert np.array_equal(t.cut_camera(world, thr, 45.0, 1.5), reference.octree_get_indices(ref["handle"], world, thr, 45.0, 1.5))
+    reference.release(ref["handle"])
+    t.close()
+
+
+@pytest.mark.parametrize("case", ["lattice", "duplicates", "three"])
+def test_hc_build_matches_live_reference(pkg, oracle, reference, synth, case):
+    """Equal pair errors are decided by the heap's internal order: the candidate heap must evolve exactly like the
+    reference's std::priority_queue (same pushes, same comparator)."""
+    lod = _lodmod()
+    if case == "lattice":
+        raw = _lattice_raw(synth, 4, 7)
+    elif case == "duplicates":
+        raw = synth.uniform_cloud(60, seed=8).copy()
+        raw[10:20] = raw[10]                          # ten identical splats
+        raw[20:40:2, 12:] = raw[21, 12:]
+    else:
+        raw = synth.uniform_cloud(3, seed=9)
+    splats = oracle.split_to_splat(_split_from(oracle, raw))
+    ref = reference.hc_build(splats)
+    t = lod.build_hc(splats)
+    assert np.array_equal(bits(t.splats), bits(ref["splats"]))
+    assert np.array_equal(t.child2, ref["child2"]) and np.array_equal(bits(t.error), bits(ref["error"]))
+    assert np.array_equal(t.roots, ref["roots"])
+    for d in (0, 1, 5, 40, 10_000):
+        assert np.array_equal(t.cut_depth(d), reference.hc_get_indices_depth(ref["handle"], d))
+    world = np.eye(4, dtype=np.float32).reshape(-1).copy()
+    world[12:15] = [0.1, 0.2, 3.0]
+    for thr in (1e-2, 1e-4, 1e-7):
+        assert np.array_equal(t.cut_camera(world, thr), reference.hc_get_indices(ref["handle"], world, thr))
+    reference.release(ref["handle"])
+    t.close()
+
+
+def test_gridhc_build_matches_live_reference(pkg, oracle, reference, synth):
+    lod = _lodmod()
+    raw = synth.clustered_cloud(3000, seed=11, n_clusters=5)
+    splats = oracle.split_to_splat(_split_from(oracle, raw))
+    ref = reference.gridhc_build(splats, (5, 3, 4))
+    t = lod.build_gridhc(splats, (5, 3, 4))
+    assert np.array_equal(bits(t.splats), bits(ref["splats"]))
+    assert np.array_equal(t.child2, ref["child2"]) and np.array_equal(bits(t.error), bits(ref["error"]))
+    assert np.array_equal(t.roots, ref["roots"]) and np.array_equal(t.cell_root_start, ref["cell_root_start"])
+    for d in (0, 3, 100):
+        assert np.array_equal(t.cut_depth(d), reference.gridhc_get_indices_error(ref["handle"], d))
+    reference.release(ref["handle"])
+    t.close()
