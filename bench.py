@@ -2,29 +2,35 @@
 """bench.py — headline benchmark of the gsx hot path on MI355X.
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: launched by torch.distributed.run, one rank per GPU, RCCL)
+  (N > 1: launched by torch.distributed.run, one rank per GPU)
 
-Workload (BASELINE.json configs[1]): 6M-splat synthetic clustered scene, one
-1920x1080 view per step.  A *step* is one complete frame of the hot path on
-data already resident in HBM: depth keys -> stable radix sort -> projection ->
-near-to-far iterations of (occlusion-aware tile binning -> pair sort -> tile raster)
-into a device RGBA8 framebuffer (no readback).
-At N > 1 the path shards by camera view over a replicated splat set (weak
-scaling: a step is a batch of N views, one per rank, every rank at the pose of the N = 1 run so that the per-GPU work is
-fixed; --distinct-views: rank r renders pose r of the pose set) and the finished frames are
-gathered to rank 0 with RCCL inside the timed region: every rank renders into the
-slots of a batch buffer and each full batch of 8 frames goes out in one asynchronous
-gather while the next batch is rendered (multigpu.BatchedFrameGather).
+Workload (BASELINE.json configs[1]): 6M-splat synthetic clustered scene, one 1920x1080 view per step.  A *step* is
+one complete frame of the hot path on data already resident in HBM: depth keys -> stable radix sort -> projection
+-> near-to-far iterations of (occlusion-aware tile binning -> pair sort -> tile raster) into a device RGBA8
+framebuffer (no readback).
 
-Prints ONE JSON line on rank 0.  `value` = splats sorted (and drawn) per second
-over whole frames, aggregated over ranks; `fps_1080p` and the sort-only rate are
-reported next to it.  `roofline` describes the radix scatter kernel (k_radix_scatter<u32>): inside the
-timed region ONE of its launches per frame is bracketed by HIP events on the library's stream (the pass
-rotates frame by frame; bracketing every stage costs ~65 us per frame and is done on a few extra frames
-AFTER the timed region for `stage_ms`).  `cpu_baseline` times the CPU port of the reference's sortSplats
-on rank 0.
+N > 1, two shardings over a replicated splat set:
+  --shard views (default; weak scaling): a step is a batch of N views, one per rank.  Every rank renders the pose of
+      the N = 1 run so that the per-GPU work is fixed (--distinct-views: rank r renders pose r of the pose set).  The
+      frames are rendered straight into the slots of a batch buffer and each full batch of 8 frames goes to rank 0 in
+      ONE gsx_gather (grouped RCCL send / recv on the library's stream) inside the timed region.
+  --shard bands (strong scaling, BASELINE.json configs[4]): ONE 3840x2160 frame of the overlap-stress scene per step;
+      rank r sorts the (replicated) scene and renders tile band r, the bands are gathered in place into rank 0's
+      frame, and after the timed region rank 0 checks that frame byte for byte against the frame it renders alone.
+  --gather torch falls back to torch.distributed.gather; it is also used, and reported, if gsx_gather's start-up
+  self-check fails.
+
+Prints ONE JSON line on rank 0.  `value` = splats sorted (and drawn) per second over whole frames, aggregated over
+ranks.  Beside the headline (one pose, history-driven schedule) the line carries `ms_per_step_no_history` (same pose,
+every iteration pre-queued) and `ms_per_step_orbit` (120-frame orbit, a new pose every step) at N = 1.
+`roofline` describes the radix scatter kernel (k_radix_scatter<u32>): inside the timed region ONE of its launches per
+frame — or, in every fourth frame, keys + sort as a whole — is bracketed by HIP events on the library's stream; pass 0
+reads no index array and is priced at its real 12 B per key.  `roofline_raster`, the per-stage breakdown and the
+rasterizer's shade / blend counts come from a few extra frames after the timed region with every stage bracketed.
+`cpu_baseline` times the CPU port of the reference's sortSplats on rank 0.
 """
 import argparse
+import csv
 import importlib
 import importlib.util
 import json
@@ -36,16 +42,22 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-SCATTER_BYTES_PER_SPLAT = 16    # one k_radix_scatter launch: read key+index (8 B), write key+index (8 B)
+VALU_PEAK_TFLOPS = 157.3        # f32 vector peak, packed or not (MI355X_MICROARCH.md, chip-level parameters)
+LDS_PEAK_GBS = 256 * 256 * 2.4  # 256 B/clk/CU x 256 CUs x 2.4 GHz
+SCATTER_BYTES_PASS0 = 12        # k_radix_scatter<u32, iota>: read key (4 B), write key + index (8 B)
+SCATTER_BYTES_PASSN = 16        # passes >= 1: read key + index (8 B), write key + index (8 B)
 KEYGEN_BYTES_PER_SPLAT = 20     # float4 position read + u32 key write (pass-0 digit count fused, no extra bytes)
 COUNT_BYTES_PER_SPLAT = 4       # k_radix_hist of passes >= 1: key read
+BLEND_FLOP = 14                 # per pixel-splat blend: uv (5), r2 + scale (4), alpha (1), weight (1), 3 colour FMAs + T (4), 1 exp beside
+SHADE_LDS_BYTES = 48            # per (wave, splat) visit: centre/extents, uv matrix, colour records read from LDS
 
 
-def sort_bytes_per_splat(passes):
-    """Algorithmic HBM bytes per splat of keys + sort: SURVEY 8(d) counts 92 B for
-    a 4-pass onesweep; this design runs `passes` scatter passes plus a 4-B count read for every pass but
-    the first."""
-    return KEYGEN_BYTES_PER_SPLAT + passes * SCATTER_BYTES_PER_SPLAT + max(passes - 1, 0) * COUNT_BYTES_PER_SPLAT
+def sort_bytes_per_splat(passes, iota=True):
+    """Algorithmic HBM bytes per splat of keys + sort."""
+    if passes <= 0:
+        return KEYGEN_BYTES_PER_SPLAT
+    first = SCATTER_BYTES_PASS0 if iota else SCATTER_BYTES_PASSN
+    return KEYGEN_BYTES_PER_SPLAT + first + (passes - 1) * (SCATTER_BYTES_PASSN + COUNT_BYTES_PER_SPLAT)
 
 
 def load_pkg():
@@ -74,11 +86,15 @@ def orbit_views(pkg, n_views, width, height):
     return views
 
 
-class DevArray:
-    """Zero-copy torch view of a raw device pointer (framebuffer) via __cuda_array_interface__."""
-
-    def __init__(self, ptr, nbytes):
-        self.__cuda_array_interface__ = {"data": (ptr, False), "shape": (nbytes,), "typestr": "|u1", "version": 2}
+def orbit_path(pkg, frames, width, height):
+    """The 120-frame orbit of SURVEY 8d cfg 3: the orbit node rotated about +Y by 2 pi / frames per frame (Node::rotate)."""
+    cam = importlib.import_module("gaussian_splatting_amd.camera")
+    step = 2.0 * np.pi / frames
+    out = []
+    for s in range(frames):
+        world = cam.orbit_pose(5.0, [((0.0, 1.0, 0.0), step)] * s)
+        out.append(cam.camera_matrices(world, 45.0, width / height))
+    return out
 
 
 def cpu_baseline(splats, views, n_frames):
@@ -106,6 +122,26 @@ def cpu_baseline_parallel(splats, views, n_frames, threads):
     return splats.shape[0] * n_frames / secs, secs
 
 
+def kernel_rooflines_from_profile(n_splats):
+    """HBM rates of the key / count / cull+projection kernels from the committed rocprofv3 --kernel-trace --stats summary of
+    this command (profiles/r2_bench_kernel_stats.csv).  Not measured in this run: the file is cited with every figure."""
+    path = os.path.join(ROOT, "profiles", "r2_bench_kernel_stats.csv")
+    if not os.path.exists(path):
+        return None
+    bytes_per_call = {   # algorithmic bytes per launch at n_splats splats (DESIGN.md section 4)
+        "k_keygen_hist0": KEYGEN_BYTES_PER_SPLAT * n_splats,
+        "k_radix_hist<unsigned int": COUNT_BYTES_PER_SPLAT * n_splats,
+    }
+    out = {"source": "profiles/r2_bench_kernel_stats.csv (rocprofv3 --kernel-trace --stats of `python bench.py --cpu-frames 0`; not measured in this run)"}
+    for r in csv.DictReader(open(path)):
+        for key, b in bytes_per_call.items():
+            if key in r["Name"]:
+                avg_us = float(r["AverageNs"]) / 1e3
+                out[key.split("<")[0]] = {"avg_us": avg_us, "calls": int(r["Calls"]), "algorithmic_bytes": b,
+                                          "hbm_gbs": b / (avg_us * 1e-6) / 1e9, "hbm_frac": b / (avg_us * 1e-6) / 1e9 / HBM_PEAK_GBS}
+    return out
+
+
 def _dbg(msg):
     if os.environ.get("GSX_BENCH_DEBUG"):
         print(f"[bench {time.perf_counter():.3f}] {msg}", file=sys.stderr, flush=True)
@@ -117,17 +153,26 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--splats", type=int, default=6_000_000)
-    ap.add_argument("--width", type=int, default=1920)
-    ap.add_argument("--height", type=int, default=1080)
-    ap.add_argument("--scene", default="clustered")
+    ap.add_argument("--width", type=int, default=None)
+    ap.add_argument("--height", type=int, default=None)
+    ap.add_argument("--scene", default=None)
+    ap.add_argument("--shard", choices=("views", "bands"), default="views")
     ap.add_argument("--cpu-frames", type=int, default=20, help="frames of the CPU baseline (0 = skip)")
-    ap.add_argument("--no-gather", action="store_true")
-    ap.add_argument("--distinct-views", action="store_true", help="N > 1: rank r renders pose r instead of the N = 1 pose")
-    ap.add_argument("--gather-batch", type=int, default=8, help="frames per RCCL gather at N > 1")
+    ap.add_argument("--gather", choices=("gsx", "torch", "none"), default="gsx")
+    ap.add_argument("--no-gather", action="store_true", help="same as --gather none")
+    ap.add_argument("--distinct-views", action="store_true", help="N > 1, views: rank r renders pose r instead of the N = 1 pose")
+    ap.add_argument("--gather-batch", type=int, default=8, help="frames per gather at N > 1 (views)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the no-history / orbit / stage measurements after the timed region")
     ap.add_argument("--opt", action="append", default=[], help="name=value for gsx_set_option (A/B runs; not used by the driver)")
     a = ap.parse_args()
+    if a.no_gather:
+        a.gather = "none"
+    bands_mode = a.shard == "bands"
+    W = a.width or (3840 if bands_mode else 1920)
+    H = a.height or (2160 if bands_mode else 1080)
+    scene_name = a.scene or ("overlap" if bands_mode else "clustered")
 
-    # stdout carries exactly ONE line, the JSON: libraries that print banners to stdout (RCCL prints its version when the
+    # stdout carries exactly ONE line, the JSON: libraries that print banners to stdout (RCCL prints its version when a
     # communicator is created) are sent to stderr by swapping the descriptors before anything is loaded
     sys.stdout.flush()
     json_fd = os.dup(1)
@@ -147,58 +192,118 @@ def main():
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback)"
+    dev = torch.device("cuda", local_rank)
     _dbg(f"process group ready: rank {rank}/{world}")
 
     pkg = load_pkg()
     synth = importlib.import_module("gaussian_splatting_amd.synth")
     scene = importlib.import_module("gaussian_splatting_amd.scene")
-    raw = synth.SCENES[a.scene](a.splats)
-    splats = scene.raw_to_splats(pkg, raw, center=False)      # host half of ResourceManager (libgsx, C++)
-    W, H = a.width, a.height
-    views = orbit_views(pkg, 64, W, H)
-    # view-batch sharding (weak scaling): a step of the job is a batch of N views, one per GPU (independent units, no
-    # data-path collective until the finished frames are gathered)
     mg = importlib.import_module("gaussian_splatting_amd.multigpu")
-    # Poses differ a lot in cost on this scene (0.41 .. 0.74 ms over the first 8, DESIGN.md section 5: tile pairs, and a camera
-    # inside the scene box needs a 4th radix pass), which would show up as a scaling loss that has nothing to do with N.
-    # Weak scaling wants the per-GPU work fixed, so by default every rank renders the pose of the N = 1 run into its own
-    # frame buffers; --distinct-views gives rank r pose r of the set instead.
-    my_views = [views[mg.shard_views(len(views), rank, max(world, 1))[0] if a.distinct_views else 0]]
+    raw = synth.SCENES[scene_name](a.splats)
+    splats = scene.raw_to_splats(pkg, raw, center=False)      # host half of ResourceManager (libgsx, C++)
+    views = orbit_views(pkg, 64, W, H)
+    # Poses differ a lot in cost on this scene (0.41 .. 0.74 ms over the first 8), which would show up
+    # as a scaling loss that has nothing to do with N.  Weak scaling wants the per-GPU work fixed, so by default every rank
+    # renders the pose of the N = 1 run; --distinct-views gives rank r pose r of the set instead.
+    my_view = views[mg.shard_views(len(views), rank, max(world, 1))[0] if (a.distinct_views and not bands_mode) else 0]
     g = pkg.Gsx(local_rank)
     g.upload(splats)
     for o in a.opt:
         k, v = o.split("=")
         g.set_option(k, int(v))
-    g.set_profiling(2)          # sampled: one k_radix_scatter launch per frame carries HIP events
-    uniforms = [pkg.make_uniforms(v[1], v[0]) for v in my_views]
-
+    g.set_profiling(2)          # sampled: one k_radix_scatter launch (or the whole sort) per frame carries HIP events
+    u_mine = pkg.make_uniforms(my_view[1], my_view[0])
     fb_bytes = W * H * 4
-    # N > 1: every rank renders straight into the slots of a batch buffer; a full batch (8 frames, SURVEY 8e cfg 4)
-    # goes to rank 0 in one asynchronous RCCL gather while the next batch is rendered (two buffers alternate).
-    bg = None
-    if dist is not None and not a.no_gather:
-        ext = torch.cuda.ExternalStream(g.stream(), device=torch.device("cuda", local_rank))
-        bg = mg.BatchedFrameGather(dist, rank, world, fb_bytes, a.gather_batch, torch.device("cuda", local_rank), stream=ext)
-    frame_no = 0
+    bands = mg.shard_bands(H, max(world, 1))
+    y0, y1 = bands[rank] if bands_mode else (0, H)
 
-    def step(i):
+    # ---- the exchange: gsx_gather (RCCL point-to-point on the library's stream), checked once before it is trusted ----
+    gather_kind, gather_note = "none", None
+    if dist is not None and a.gather != "none":
+        gather_kind = a.gather
+        if a.gather == "gsx":
+            try:
+                idt = torch.zeros(128, dtype=torch.uint8, device=dev)
+                if rank == 0 and world > 1:
+                    idt.copy_(torch.from_numpy(g.comm_unique_id()))
+                if world > 1:
+                    dist.broadcast(idt, 0)
+                g.comm_init(idt.cpu().numpy() if world > 1 else None, rank, world)
+                probe = torch.full((4096,), rank + 1, dtype=torch.uint8, device=dev)
+                sink = torch.zeros(4096 * world, dtype=torch.uint8, device=dev) if rank == 0 else None
+                torch.cuda.synchronize()
+                g.gather(probe.data_ptr(), 4096, sink.data_ptr() if rank == 0 else None,
+                         [4096 * r for r in range(world)] if rank == 0 else None, [4096] * world if rank == 0 else None, 0)
+                g.sync()
+                ok = 1
+                if rank == 0:
+                    got = sink.cpu().numpy().reshape(world, 4096)
+                    ok = int(all(np.all(got[r] == r + 1) for r in range(world)))
+            except Exception as e:      # noqa: BLE001 — any failure here means: do not use this path
+                ok, gather_note = 0, f"gsx_gather unavailable on rank {rank}: {e}"
+            flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) != 1:
+                gather_kind = "torch"
+                gather_note = gather_note or "gsx_gather self-check failed on some rank; fell back to torch.distributed.gather"
+    _dbg(f"gather: {gather_kind}")
+
+    keep = []
+
+    def alloc(nbytes):
+        t = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
+        keep.append(t)
+        return t.data_ptr(), t
+
+    fg = None      # view batches through gsx_gather
+    bg = None      # view batches through torch.distributed
+    if not bands_mode and gather_kind == "gsx":
+        fg = mg.GsxFrameGather(g, rank, world, fb_bytes, a.gather_batch, alloc)
+    elif not bands_mode and gather_kind == "torch":
+        ext = torch.cuda.ExternalStream(g.stream(), device=dev)
+        bg = mg.BatchedFrameGather(dist, rank, world, fb_bytes, a.gather_batch, dev, stream=ext)
+    band_recv = [torch.zeros(fb_bytes, dtype=torch.uint8, device=dev) for _ in range(world)] if (bands_mode and gather_kind == "torch" and rank == 0) else None
+    frame_no = 0
+    exchange = True     # switched off after the timed region: what follows is rank 0's alone
+
+    def step(pose=None, uniforms=None):
         nonlocal frame_no
-        v = i % len(my_views)
-        g.sort(my_views[v][2], download=False)          # queued behind the running frame
-        if bg is not None:
-            slot = bg.slot(frame_no)
-            g.set_framebuffer_dev(slot.data_ptr(), fb_bytes)   # completes the previous frame into ITS slot first
-            if frame_no:
-                bg.frame_done(frame_no - 1)             # closes a batch every gather_batch frames: async gather
-        g.render(uniforms[v], W, H, download=False)
+        pos = my_view[2] if pose is None else pose
+        uni = u_mine if uniforms is None else uniforms
+        g.sort(pos, download=False)          # queued behind the running frame
+        if bands_mode:
+            if y1 > y0:
+                g.render(uni, W, H, y0, y1, download=False)
+            if not exchange:
+                pass
+            elif gather_kind == "gsx":
+                fb_ptr = g.framebuffer_dev()[0]
+                mg.gather_bands_gsx(g, fb_ptr, bands, W, rank)
+            elif gather_kind == "torch":
+                g.sync()
+                fb_ptr = g.framebuffer_dev()[0]
+                t = torch.as_tensor(DevArray(fb_ptr, fb_bytes), device=dev)
+                mg.gather_to_rank0(dist, t, rank, world, band_recv)
+        else:
+            batcher = fg or bg
+            if batcher is not None:
+                slot = batcher.slot(frame_no)
+                if fg is not None:
+                    g.set_framebuffer_dev(slot, fb_bytes)              # completes the previous frame into ITS slot first
+                else:
+                    g.set_framebuffer_dev(slot.data_ptr(), fb_bytes)
+                if frame_no:
+                    batcher.frame_done(frame_no - 1)                   # closes a batch every gather_batch frames
+            g.render(uni, W, H, download=False)
         frame_no += 1
 
     def drain():
-        """Complete the last frame and send what is left of the current batch; waits for every gather."""
-        if bg is not None and frame_no:
+        """Complete the last frame and send what is left of the current batch."""
+        batcher = fg or bg
+        if batcher is not None and frame_no:
             g.set_framebuffer_dev(None)
-            bg.frame_done(frame_no - 1)
-            bg.finish()
+            batcher.frame_done(frame_no - 1)
+            batcher.finish()
 
     def fence():
         if dist is not None:
@@ -208,92 +313,173 @@ def main():
 
     _dbg("scene uploaded")
     for i in range(a.warmup):
-        step(i)
+        step()
     fence()
     _dbg("warm-up done")
     g.scatter_samples(reset=True)
-    # Frames are queued back to back (the next frame's sort is queued behind the running frame; gsx_render waits for
-    # the previous frame only to check whether it needs more iterations).  Nothing is read back inside the loop: the
-    # sampled scatter launches sit in the library's event ring and are collected after the closing fence.
+    g.sort_samples(reset=True)
+    # Frames are queued back to back (the next frame's sort is queued behind the running frame; gsx_render waits for the
+    # previous frame only to check whether it needs more iterations).  Nothing is read back inside the loop: the sampled
+    # launches sit in the library's event ring and are collected after the closing fence.
     t0 = time.perf_counter()
     for i in range(a.steps):
-        step(i)
-        if i % 16 == 15:
-            _dbg(f"queued step {i}")
-    _dbg("timed steps queued")
+        step()
     drain()
-    _dbg("drained")
     fence()
     elapsed = time.perf_counter() - t0
     _dbg("timed region closed")
-    bg = None                                            # the extra profiling frames below are rank 0's alone: no collective
     per_pass, pass_n = g.scatter_samples(reset=True)     # mean launch duration of each radix pass over the timed region
+    sort_ms_timed, sort_n_timed = g.sort_samples(reset=True)
     t = g.timings()
-    pairs = t["tile_pairs"] * a.steps; iters = t["render_iters"] * a.steps; passes = t["sort_passes"] * a.steps
+    pairs, iters, passes = t["tile_pairs"], t["render_iters"], t["sort_passes"]
     if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=torch.device("cuda", local_rank))
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
-    # stage breakdown on a few extra frames with every stage bracketed (outside the timed region)
-    acc = {}
-    n_prof = 6
-    if rank == 0:
+    # ---- bands: rank 0's gathered frame against the frame it renders alone (frames are a pure function of scene,
+    #      permutation and uniforms, so the composition must be byte-identical) ----
+    bands_match = None
+    if bands_mode and rank == 0:
+        g.sync()
+        import ctypes as C
+        hip = C.CDLL("libamdhip64.so")
+        gathered = np.empty(fb_bytes, np.uint8)
+        if gather_kind == "torch":
+            gathered = mg.compose_bands(band_recv, bands, W).cpu().numpy()
+        else:
+            hip.hipMemcpy(C.c_void_p(gathered.ctypes.data), C.c_void_p(g.framebuffer_dev()[0]), C.c_size_t(fb_bytes), C.c_int(2))
+        g.sort(my_view[2], download=False)
+        alone = g.render(u_mine, W, H).reshape(-1)
+        bands_match = bool(np.array_equal(gathered, alone)) if (world == 1 or gather_kind != "none") else None
+    fg = bg = None                                       # everything below is rank 0's alone: no collective
+    exchange = False
+
+    # ---- beside the headline, N = 1 only: no history, and a moving camera ----
+    extras = {}
+    acc, n_prof = {}, 6
+    if rank == 0 and not a.no_extras:
+        g.set_framebuffer_dev(None)
+        if world == 1 and not bands_mode:
+            K2 = max(10, min(a.steps, 40))
+            g.set_option("no_history", 1)
+            for i in range(3):
+                step()
+            g.sync()
+            t1 = time.perf_counter()
+            for i in range(K2):
+                step()
+            g.sync()
+            extras["ms_per_step_no_history"] = (time.perf_counter() - t1) / K2 * 1e3
+            g.set_option("no_history", 0)
+            path = orbit_path(pkg, 120, W, H)
+            unis = [pkg.make_uniforms(p[1], p[0]) for p in path]
+            for i in range(4):
+                step(path[i][2], unis[i])
+            g.sync()
+            t1 = time.perf_counter()
+            for i in range(120):
+                step(path[i][2], unis[i])
+            g.sync()
+            extras["ms_per_step_orbit"] = (time.perf_counter() - t1) / 120 * 1e3
+            extras["orbit_note"] = "120-frame orbit about +Y (2 pi / 120 per frame), a new pose every step, default history-driven schedule"
+        # stage breakdown on a few extra frames with every stage bracketed (outside the timed region)
         g.set_profiling(1)
         for i in range(n_prof + 1):
-            step(i)
-            t = g.timings()
+            step()
+            tm = g.timings()
             if i:                                  # first frame after switching levels is a warm-up
-                for k, val in t.items():
+                for k, val in tm.items():
                     acc[k] = acc.get(k, 0.0) + val
 
     if rank == 0:
-        K = a.steps
-        n = a.splats
-        passes_per_frame = passes / K
-        launch_ms = sum(per_pass.values()) / max(len(per_pass), 1)       # average k_radix_scatter<u32> launch
-        achieved = SCATTER_BYTES_PER_SPLAT * n / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
-        keysort_ms = (acc["keygen_ms"] + acc["sort_ms"]) / n_prof
-        sort_bytes = sort_bytes_per_splat(int(round(passes_per_frame)))
-        traffic = None
-        tf = os.path.join(ROOT, "profiles", "r1_scatter_traffic.json")     # PMC passes (tools/pmc_traffic.sh), committed
+        K, n = a.steps, a.splats
+        frames_total = K * (1 if bands_mode else world)
+        n_pass = int(round(passes))
+        # the roofline kernel: every sampled launch priced at its own bytes (pass 0 generates the index: 12 B per key)
+        launch_bytes = {p: (SCATTER_BYTES_PASS0 if p == 0 else SCATTER_BYTES_PASSN) * n for p in per_pass}
+        sum_ms = sum(per_pass[p] * pass_n[p] for p in per_pass)
+        sum_bytes = sum(launch_bytes[p] * pass_n[p] for p in per_pass)
+        launches = sum(pass_n.values())
+        launch_ms = sum_ms / launches if launches else 0.0
+        achieved = sum_bytes / (sum_ms * 1e-3) / 1e9 if sum_ms > 0 else 0.0
+        sort_bytes = sort_bytes_per_splat(n_pass)
+        traffic, traffic_src = None, None
+        tf = os.path.join(ROOT, "profiles", "r2_scatter_traffic.json")     # PMC passes (tools/pmc_traffic.sh), committed
         if os.path.exists(tf):
             rec = json.load(open(tf))
             if rec.get("splats") == n:
                 traffic = rec.get("hbm_bytes_per_launch")
+                traffic_src = "profiles/r2_scatter_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (tools/pmc_traffic.sh), not measured in this run"
         out = {
-            "metric": "splats_sorted_per_s (whole 1080p frame: keys+sort+project+bin+raster)",
-            "value": n * K * world / elapsed,
+            "metric": f"splats_sorted_per_s (whole {W}x{H} frame: keys+sort+project+bin+raster)",
+            "value": n * frames_total / elapsed,
             "unit": "splats/s",
             "n_gpus": world,
             "steps": K,
             "warmup": a.warmup,
             "ms_per_step": elapsed / K * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if bands_mode else "weak",
             "vs_baseline": None,
             "dtype": "f32 keys / u32 radix",
             "data": "synthetic",
-            "config": {"workload": f"cfg2: {n}-splat clustered synthetic scene, single view {W}x{H} per step",
-                       "splats": n, "width": W, "height": H, "views_per_step_per_gpu": 1,
-                       "poses": "rank r renders pose r" if a.distinct_views else "every rank renders the N=1 pose (fixed per-GPU work)",
-                       "sharding": "camera views over replicated splats" + ("" if a.no_gather or world == 1 else f" + RCCL framebuffer gather to rank 0 in batches of {a.gather_batch} frames")},
-            "fps_1080p": K * world / elapsed,
-            "sort_only_splats_per_s": n / (keysort_ms * 1e-3),
-            "sort_only_ms": keysort_ms,
-            "sort_only_bytes_per_splat": sort_bytes,
-            "sort_only_hbm_frac": sort_bytes * n / (keysort_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-            "sort_only_hbm_frac_at_92B": 92 * n / (keysort_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-            "stage_ms": {k: acc[k] / n_prof for k in ("select_ms", "keygen_ms", "sort_ms", "scatter_ms", "project_ms", "bin_ms", "raster_ms", "total_ms")},
-            "stage_ms_note": f"{n_prof} extra frames after the timed region with every stage bracketed by HIP events (adds ~65 us per frame)",
-            "tile_pairs": int(pairs / K),
-            "render_iters": iters / K,
+            "config": {"workload": (f"cfg5: {n}-splat overlap-stress scene, ONE {W}x{H} frame per step in {world} tile band(s)" if bands_mode else
+                                    f"cfg2: {n}-splat clustered synthetic scene, single view {W}x{H} per step"),
+                       "splats": n, "width": W, "height": H, "views_per_step_per_gpu": None if bands_mode else 1,
+                       "poses": "one pose" if bands_mode else ("rank r renders pose r" if a.distinct_views else "every rank renders the N=1 pose (fixed per-GPU work)"),
+                       "sharding": ("screen-space tile bands over replicated splats" if bands_mode else "camera views over replicated splats"),
+                       "gather": {"gsx": f"gsx_gather (grouped RCCL send/recv on the library's stream)" + ("" if bands_mode else f", batches of {a.gather_batch} frames"),
+                                  "torch": "torch.distributed.gather (nccl = RCCL)", "none": "none"}[gather_kind]},
+            "fps": frames_total / elapsed,
+            "tile_pairs": int(pairs),
+            "render_iters": iters,
+            "sort_passes": n_pass,
             "roofline": {"kernel": "k_radix_scatter<u32> (one stable radix scatter pass of the depth sort)", "bound": "hbm", "achieved": achieved,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "avg_launch_ms": launch_ms, "per_pass_launch_ms": [per_pass[p] for p in sorted(per_pass)],
-                         "launches_per_step": passes_per_frame, "launches_timed": int(sum(pass_n.values())),
-                         "algorithmic_bytes_per_launch": SCATTER_BYTES_PER_SPLAT * n},
+                         "per_pass_bytes": [launch_bytes[p] for p in sorted(per_pass)],
+                         "launches_per_step": n_pass, "launches_timed": int(launches),
+                         "algorithmic_bytes_per_launch": sum_bytes / launches if launches else None,
+                         "note": "HIP events on the library's stream inside the timed region, one launch per frame, pass rotating; pass 0 priced at 12 B/key, passes >= 1 at 16 B/key"},
         }
+        if not bands_mode:
+            out["fps_1080p"] = out["fps"]
+        if gather_note:
+            out["config"]["gather_note"] = gather_note
+        if bands_match is not None:
+            out["bands_match_single_gpu_frame"] = bands_match
+        if sort_n_timed:
+            out["sort_only_ms"] = sort_ms_timed
+            out["sort_only_samples"] = sort_n_timed
+            out["sort_only_note"] = "keys + sort bracketed as a whole by HIP events in every (passes+1)-th frame INSIDE the timed region"
+            out["sort_only_splats_per_s"] = n / (sort_ms_timed * 1e-3)
+            out["sort_only_bytes_per_splat"] = sort_bytes
+            out["sort_only_hbm_frac"] = sort_bytes * n / (sort_ms_timed * 1e-3) / 1e9 / HBM_PEAK_GBS
+            out["sort_only_hbm_frac_at_92B"] = 92 * n / (sort_ms_timed * 1e-3) / 1e9 / HBM_PEAK_GBS
+        out.update(extras)
+        if acc:
+            stage = {k: acc[k] / n_prof for k in ("select_ms", "keygen_ms", "sort_ms", "scatter_ms", "project_ms", "bin_ms", "raster_ms", "total_ms")}
+            out["stage_ms"] = stage
+            out["stage_ms_note"] = f"{n_prof} extra frames after the timed region with every stage bracketed by HIP events (adds ~65 us per frame)"
+            shades, blends = acc["raster_shades"] / n_prof, acc["raster_blends"] / n_prof
+            r_ms = stage["raster_ms"]
+            if r_ms > 0:
+                out["roofline_raster"] = {
+                    "kernel": "k_raster (tile rasterizer, all iterations of a frame)", "bound": "valu (packed f32) + lds",
+                    "raster_ms": r_ms, "wave_splat_shades": shades, "pixel_blends": blends,
+                    "blends_per_s": blends / (r_ms * 1e-3),
+                    "lane_hit_rate": blends / (shades * 128.0) if shades else None,
+                    "valu_tflops": blends * BLEND_FLOP / (r_ms * 1e-3) / 1e12,
+                    "valu_tflops_issued": shades * 128 * BLEND_FLOP / (r_ms * 1e-3) / 1e12,
+                    "valu_peak_tflops": VALU_PEAK_TFLOPS,
+                    "valu_frac_issued": shades * 128 * BLEND_FLOP / (r_ms * 1e-3) / 1e12 / VALU_PEAK_TFLOPS,
+                    "lds_gbs": shades * SHADE_LDS_BYTES / (r_ms * 1e-3) / 1e9, "lds_peak_gbs": LDS_PEAK_GBS,
+                    "note": f"{BLEND_FLOP} flop per pixel-splat blend (+1 v_exp_f32); 'issued' counts all 128 pixels of a wave per visited splat (masked lanes still occupy the SIMD); "
+                            f"LDS: {SHADE_LDS_BYTES} B of broadcast record reads per (wave, splat) visit; counters from the {n_prof} profiled frames"}
+        kr = kernel_rooflines_from_profile(n) if not bands_mode else None
+        if kr:
+            out["kernel_rooflines"] = kr
         if a.cpu_frames > 0:
             v, secs = cpu_baseline(splats, views, a.cpu_frames)
             out["cpu_baseline"] = {"value": v, "unit": "splats/s", "cores": 1, "kind": "port",
@@ -313,10 +499,18 @@ def main():
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     _dbg("closing")
-    g.close()
     if dist is not None:
         dist.barrier()
+    g.close()
+    if dist is not None:
         dist.destroy_process_group()
+
+
+class DevArray:
+    """Zero-copy torch view of a raw device pointer (framebuffer) via __cuda_array_interface__."""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"data": (ptr, False), "shape": (nbytes,), "typestr": "|u1", "version": 2}
 
 
 if __name__ == "__main__":

@@ -20,10 +20,11 @@ GSX_OK, GSX_E_INVALID, GSX_E_HIP, GSX_E_NOMEM, GSX_E_STATE, GSX_E_UNSUPPORTED, G
 
 # every symbol include/gsx.h declares
 ABI_SYMBOLS = [
-    "gsx_create", "gsx_destroy", "gsx_last_error", "gsx_sync", "gsx_set_profiling", "gsx_get_timings", "gsx_get_scatter_samples", "gsx_set_option",
+    "gsx_create", "gsx_destroy", "gsx_last_error", "gsx_sync", "gsx_set_profiling", "gsx_get_timings", "gsx_get_scatter_samples", "gsx_get_sort_samples", "gsx_set_option",
     "gsx_upload_splats", "gsx_upload_splats_dev", "gsx_select_all", "gsx_select_list", "gsx_set_lod_octree",
     "gsx_set_lod_hc", "gsx_select_octree", "gsx_select_hc", "gsx_get_selection", "gsx_sort", "gsx_sort_noalloc", "gsx_get_sorted_dev",
     "gsx_get_keys", "gsx_render", "gsx_get_framebuffer_dev", "gsx_set_framebuffer_dev", "gsx_get_stream",
+    "gsx_comm_unique_id", "gsx_comm_init", "gsx_comm_destroy", "gsx_gather",
     "gsx_host_convert_raw", "gsx_host_load_splat_file", "gsx_host_free", "gsx_host_load_ply_raw", "gsx_host_load_ply_file", "gsx_host_camera", "gsx_host_orbit_pose",
     "gsx_host_octree_build", "gsx_host_hc_build", "gsx_host_gridhc_build", "gsx_host_lod_free", "gsx_host_lod_size",
     "gsx_host_lod_roots", "gsx_host_lod_cells", "gsx_host_lod_splats", "gsx_host_lod_flat_octree", "gsx_host_lod_flat_hc",
@@ -51,7 +52,8 @@ class HcFlat(C.Structure):
 class Timings(C.Structure):
     _fields_ = [("select_ms", C.c_float), ("keygen_ms", C.c_float), ("sort_ms", C.c_float), ("scatter_ms", C.c_float), ("project_ms", C.c_float),
                 ("bin_ms", C.c_float), ("raster_ms", C.c_float), ("total_ms", C.c_float), ("sort_passes", C.c_uint32),
-                ("sort_launches", C.c_uint32), ("tile_pairs", C.c_uint64), ("render_iters", C.c_uint32), ("scatter_sample", C.c_uint32)]
+                ("sort_launches", C.c_uint32), ("tile_pairs", C.c_uint64), ("render_iters", C.c_uint32), ("scatter_sample", C.c_uint32),
+                ("raster_shades", C.c_uint64), ("raster_blends", C.c_uint64)]
 
 
 assert C.sizeof(Uniforms) == 224
@@ -107,6 +109,7 @@ class Gsx:
 
     def close(self):
         if self.ctx:
+            self.comm_destroy()
             self.lib.gsx_destroy(self.ctx)
             self.ctx = C.c_void_p()
 
@@ -223,6 +226,35 @@ class Gsx:
         self._chk(self.lib.gsx_get_stream(self.ctx, C.byref(st)))
         return st.value or 0
 
+    # -- multi-GPU gather (include/gsx.h: gsx_comm_*, gsx_gather) --
+    def comm_unique_id(self):
+        """128-byte RCCL id (rank 0 creates it and hands it to the other ranks)."""
+        buf = np.zeros(128, np.uint8)
+        rc = self.lib.gsx_comm_unique_id(_ptr(buf))
+        if rc != GSX_OK:
+            raise GsxError(rc, "gsx_comm_unique_id failed (librccl missing?)")
+        return buf
+
+    def comm_init(self, id128, rank, nranks):
+        """Collective: joins the communicator of `nranks` processes.  Kept in self.comm until close()."""
+        comm = C.c_void_p()
+        idp = None if id128 is None else _ptr(np.ascontiguousarray(id128, np.uint8))
+        self._chk(self.lib.gsx_comm_init(self.ctx, idp, C.c_int(rank), C.c_int(nranks), C.byref(comm)))
+        self.comm, self.comm_rank, self.comm_size = comm, rank, nranks
+        return comm
+
+    def comm_destroy(self):
+        if getattr(self, "comm", None):
+            self.lib.gsx_comm_destroy(self.comm)
+            self.comm = None
+
+    def gather(self, send_dev_ptr, send_bytes, recv_dev_ptr=None, recv_offsets=None, recv_bytes=None, root=0):
+        """gsx_gather on this context's stream (device pointers as integers)."""
+        off = None if recv_offsets is None else np.ascontiguousarray(recv_offsets, np.uint64)
+        cnt = None if recv_bytes is None else np.ascontiguousarray(recv_bytes, np.uint64)
+        self._chk(self.lib.gsx_gather(self.ctx, self.comm, C.c_void_p(send_dev_ptr), C.c_uint64(int(send_bytes)),
+                                      C.c_void_p(recv_dev_ptr), _ptr(off), _ptr(cnt), C.c_int(root)))
+
     # -- misc --
     def sync(self):
         self._chk(self.lib.gsx_sync(self.ctx))
@@ -240,6 +272,12 @@ class Gsx:
         cnt = (C.c_uint32 * 4)()
         self._chk(self.lib.gsx_get_scatter_samples(self.ctx, sums, cnt, C.c_int(1 if reset else 0)))
         return ({p: sums[p] / cnt[p] for p in range(4) if cnt[p]}, {p: int(cnt[p]) for p in range(4) if cnt[p]})
+
+    def sort_samples(self, reset=True):
+        """Profiling level 2: (mean ms of keys + sort as a whole, number of sampled sorts)."""
+        s, n = C.c_double(0.0), C.c_uint32(0)
+        self._chk(self.lib.gsx_get_sort_samples(self.ctx, C.byref(s), C.byref(n), C.c_int(1 if reset else 0)))
+        return (s.value / n.value if n.value else 0.0), int(n.value)
 
     def timings(self):
         t = Timings()

@@ -110,6 +110,7 @@ int gsx_create(int device, gsx_ctx** out) {
     if (hipHostMalloc(reinterpret_cast<void**>(&c->ctl_host), GSX_AUX_OFFSET + 128, hipHostMallocDefault) != hipSuccess)
         return fail(GSX_E_NOMEM);
     c->aux_host = reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(c->ctl_host) + GSX_AUX_OFFSET);
+    if (hipMalloc(reinterpret_cast<void**>(&c->stat), GSX_STAT_BYTES) != hipSuccess) return fail(GSX_E_NOMEM);
     if (hipMalloc(reinterpret_cast<void**>(&c->m_dev), 16) != hipSuccess) return fail(GSX_E_NOMEM);
     if (hipMalloc(reinterpret_cast<void**>(&c->aabb_dev), 32) != hipSuccess) return fail(GSX_E_NOMEM);
     if (hipMalloc(reinterpret_cast<void**>(&c->flags), sizeof(GsxDevFlags)) != hipSuccess) return fail(GSX_E_NOMEM);
@@ -134,7 +135,7 @@ int gsx_destroy(gsx_ctx* c) {
     dev_free(&c->lod_stop); dev_free(&c->lod_emit); dev_free(&c->lod_block_sums);
     for (int b = 0; b < 2; ++b) { dev_free(&c->keys[b]); dev_free(&c->vals[b]); dev_free(&c->perm[b]); dev_free(&c->pair_key[b]); dev_free(&c->pair_val[b]); }
     dev_free(&c->sort_ws); dev_free(&c->aabb_dev); dev_free(&c->flags); dev_free(&c->pair_ws);
-    dev_free(&c->scan_block_sums);
+    dev_free(&c->scan_block_sums); dev_free(&c->stat);
     dev_free(&c->fb);
     dev_free(&c->sub_off); dev_free(&c->rank_box); dev_free(&c->rank_rec); dev_free(&c->ctl); dev_free(&c->live_bits); dev_free(&c->tile_state); dev_free(&c->accum);
     if (c->ctl_host) (void)hipHostFree(c->ctl_host);
@@ -202,6 +203,19 @@ int gsx_get_scatter_samples(gsx_ctx* c, double sum_ms[4], uint32_t launches[4], 
     return GSX_OK;
 }
 
+int gsx_get_sort_samples(gsx_ctx* c, double* sum_ms, uint32_t* sorts, int reset) {
+    if (!c || !sum_ms || !sorts) return GSX_E_INVALID;
+    int rc = set_device(c);
+    if (rc) return rc;
+    if ((rc = gsx_frame_finish(c))) return rc;
+    GSX_HIP(c, hipStreamSynchronize(c->stream));
+    for (uint32_t k = 0; k < GSX_SAMPLE_RING; ++k) gsx_sample_drain(c, (c->samp_pos + k) % GSX_SAMPLE_RING);
+    *sum_ms = c->samp_sum_ms[GSX_SAMPLE_WHOLE];
+    *sorts = c->samp_n[GSX_SAMPLE_WHOLE];
+    if (reset) { c->samp_sum_ms[GSX_SAMPLE_WHOLE] = 0.0; c->samp_n[GSX_SAMPLE_WHOLE] = 0; }
+    return GSX_OK;
+}
+
 int gsx_get_timings(gsx_ctx* c, gsx_timings* out) {
     if (!c || !out) return GSX_E_INVALID;
     int rc = set_device(c);
@@ -229,6 +243,12 @@ int gsx_get_timings(gsx_ctx* c, gsx_timings* out) {
             }
         }
         t.total_ms = t.select_ms + t.keygen_ms + t.sort_ms + t.project_ms + t.bin_ms + t.raster_ms;
+        if (c->ev_recorded[EV_RAST1] && c->stat) {
+            std::vector<unsigned long long> st(GSX_STAT_BYTES / 8);
+            GSX_HIP(c, hipMemcpy(st.data(), c->stat, GSX_STAT_BYTES, hipMemcpyDeviceToHost));
+            t.raster_shades = 0; t.raster_blends = 0;
+            for (int sh = 0; sh < 64; ++sh) { t.raster_shades += st[sh * 16]; t.raster_blends += st[sh * 16 + 1]; }
+        }
     }
     t.scatter_sample = 0;
     if (c->prof_level == 2) {

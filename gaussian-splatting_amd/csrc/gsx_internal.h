@@ -10,6 +10,8 @@
 
 #define GSX_WAVE 64
 #define GSX_SAMPLE_RING 32
+#define GSX_SAMPLE_WHOLE 4     // sample slot of "keys + sort as a whole" (slots 0..3: the scatter launch of a radix pass)
+#define GSX_STAT_BYTES (64 * 16 * 8)   // rasterizer counters (profiling level 1): 64 shards x one 128-byte line of u64 words
 #define GSX_AUX_OFFSET 512   // bytes from the frame control block to the aux words (same allocation)
 
 // ---- sort geometry: one workgroup sorts one tile of NT*IPT keys per pass ----
@@ -101,8 +103,8 @@ struct gsx_ctx {
     hipEvent_t samp_ev[GSX_SAMPLE_RING][2] = {};
     int samp_pass[GSX_SAMPLE_RING];    // pass a slot's events bracket, -1 = slot free
     uint32_t samp_pos = 0;
-    double samp_sum_ms[4] = {0, 0, 0, 0};
-    uint32_t samp_n[4] = {0, 0, 0, 0};
+    double samp_sum_ms[GSX_SAMPLE_WHOLE + 1] = {0, 0, 0, 0, 0};
+    uint32_t samp_n[GSX_SAMPLE_WHOLE + 1] = {0, 0, 0, 0, 0};
     float samp_last_ms = 0.0f;
     int samp_last_pass = -1;
 
@@ -182,6 +184,7 @@ struct gsx_ctx {
     // atomics while tiles retire, and any load from it then queues behind them (measured: raster 3x slower).
     uint32_t* aux = nullptr;
     uint32_t* aux_host = nullptr;      // pinned, 32 words
+    unsigned long long* stat = nullptr;   // GSX_STAT_BYTES of sharded counters: [shard*16 + 0] (wave, splat) shades, [+1] pixels blended
     uint32_t* live_bits = nullptr;     // GSX_MAX_TILES_Y x GSX_LIVE_ROW_WORDS: tiles still unsaturated
     uint32_t* tile_state = nullptr;    // per tile: 0 untouched, 1 accumulators valid, 2 retired
     uint64_t tile_state_cap = 0;

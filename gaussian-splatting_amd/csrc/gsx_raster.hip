@@ -519,13 +519,15 @@ __device__ __forceinline__ uint32_t gsx_pack_rgba8(float r, float g, float b) {
 // One 128-thread workgroup per 16x16 tile.  Wave w owns the 16x8 half (rows 8w .. 8w+7); a lane owns the two
 // horizontally adjacent pixels (2*(lane&7), 2*(lane&7)+1) of row lane>>3, so that every arithmetic step of the
 // shading loop is one packed-f32 instruction for both pixels (measured: the loop is VALU-bound).
-template <int MODE /*0 blend, 1 threshold (bayerSize 10), 2 bayer dither*/>
+template <int MODE /*0 blend, 1 threshold (bayerSize 10), 2 bayer dither*/, bool COUNT /*profiling level 1: count shades and blends*/>
 __global__ __launch_bounds__(GSX_RASTER_NT) void k_raster(const uint16_t* __restrict__ pair_key, const uint32_t* __restrict__ pair_val,
                                                           const float4* __restrict__ rank_rec, uint32_t iter, GsxViewParams vp, uint32_t first,
                                                           uint32_t* __restrict__ tile_state, uint32_t* __restrict__ live_bits,
                                                           float4* __restrict__ accum, GsxFrameCtl* __restrict__ ctl,
-                                                          uint32_t* __restrict__ aux, uint8_t* __restrict__ fb) {
+                                                          uint32_t* __restrict__ aux, uint8_t* __restrict__ fb,
+                                                          unsigned long long* __restrict__ stat) {
     constexpr uint32_t NW = GSX_RASTER_NT / 64;                   // 2 waves = 2 halves
+    unsigned long long n_shades = 0, n_blends = 0;                // COUNT: (wave, splat) visits / pixels blended
     static_assert(GSX_RASTER_BATCH == GSX_RASTER_NT, "one staged splat per thread");
     __shared__ float4 s_a[GSX_RASTER_BATCH];  // cx cy ex ey
     __shared__ float4 s_m[GSX_RASTER_BATCH];  // m00 m01 m10 m11
@@ -639,6 +641,10 @@ __global__ __launch_bounds__(GSX_RASTER_NT) void k_raster(const uint16_t* __rest
                     dbg_hits += __popcll(__builtin_amdgcn_ballot_w64(h0)) + __popcll(__builtin_amdgcn_ballot_w64(h1));
                     dbg_useful += __popcll(__builtin_amdgcn_ballot_w64(h0 && T.x >= GSX_T_EPS)) + __popcll(__builtin_amdgcn_ballot_w64(h1 && T.y >= GSX_T_EPS));
 #endif
+                    if (COUNT) {
+                        ++n_shades;
+                        n_blends += __popcll(__builtin_amdgcn_ballot_w64(h0)) + __popcll(__builtin_amdgcn_ballot_w64(h1));
+                    }
                     if (h0 || h1) {
                         const float4 c = s_c[j];
                         // exp(-r2/2) = 2^(r2 * -log2(e)/2): one packed multiply for both pixels, then v_exp_f32
@@ -671,6 +677,11 @@ __global__ __launch_bounds__(GSX_RASTER_NT) void k_raster(const uint16_t* __rest
         atomicAdd(&ctl->dbg[3], (end - begin));
     }
 #endif
+    if (COUNT && lane == 0) {   // sharded over 64 cache lines: thousands of waves adding to ONE word would serialize for ~100 us
+        unsigned long long* shard = stat + (tile & 63u) * 16u;
+        atomicAdd(shard, n_shades);
+        atomicAdd(shard + 1, n_blends);
+    }
     // retire the tile or park its accumulators for the next iteration
     __syncthreads();
     if (tid == 0) s_live[1] = 0;
@@ -784,15 +795,14 @@ static int launch_iteration(gsx_ctx* c, uint32_t iter, uint32_t window, bool fir
     }
     if (c->profiling && iter < GSX_MAX_SCHED && !f.continuing) GSX_HIP(c, hipEventRecord(c->ev[EV_IT0 + 2 * iter], c->stream));
     const uint32_t fi = first ? 1u : 0u;
-    if (f.mode == 0)
-        hipLaunchKernelGGL(k_raster<0>, dim3(f.n_tiles), dim3(GSX_RASTER_NT), 0, c->stream, c->pair_key[cur], c->pair_val[cur], c->rank_rec, iter, vp,
-                           fi, c->tile_state, c->live_bits, c->accum, c->ctl, c->aux, c->fb_cur);
-    else if (f.mode == 1)
-        hipLaunchKernelGGL(k_raster<1>, dim3(f.n_tiles), dim3(GSX_RASTER_NT), 0, c->stream, c->pair_key[cur], c->pair_val[cur], c->rank_rec, iter, vp,
-                           fi, c->tile_state, c->live_bits, c->accum, c->ctl, c->aux, c->fb_cur);
-    else
-        hipLaunchKernelGGL(k_raster<2>, dim3(f.n_tiles), dim3(GSX_RASTER_NT), 0, c->stream, c->pair_key[cur], c->pair_val[cur], c->rank_rec, iter, vp,
-                           fi, c->tile_state, c->live_bits, c->accum, c->ctl, c->aux, c->fb_cur);
+    const bool count = c->profiling && c->stat != nullptr;
+#define GSX_LAUNCH_RASTER(M, CNT)                                                                                                       \
+    hipLaunchKernelGGL((k_raster<M, CNT>), dim3(f.n_tiles), dim3(GSX_RASTER_NT), 0, c->stream, c->pair_key[cur], c->pair_val[cur],    \
+                       c->rank_rec, iter, vp, fi, c->tile_state, c->live_bits, c->accum, c->ctl, c->aux, c->fb_cur, c->stat)
+    if (f.mode == 0) { if (count) GSX_LAUNCH_RASTER(0, true); else GSX_LAUNCH_RASTER(0, false); }
+    else if (f.mode == 1) { if (count) GSX_LAUNCH_RASTER(1, true); else GSX_LAUNCH_RASTER(1, false); }
+    else { if (count) GSX_LAUNCH_RASTER(2, true); else GSX_LAUNCH_RASTER(2, false); }
+#undef GSX_LAUNCH_RASTER
     if (c->profiling && iter < GSX_MAX_SCHED && !f.continuing) GSX_HIP(c, hipEventRecord(c->ev[EV_IT0 + 2 * iter + 1], c->stream));
     return GSX_OK;
 }
@@ -872,6 +882,7 @@ int gsx_launch_render(gsx_ctx* c, const gsx_uniforms* u, uint32_t w, uint32_t h,
     f.continuing = false;
 
     // (K3, the projection, runs inside k_chunk_count on the ranks each iteration reaches)
+    if (c->profiling && c->stat) GSX_HIP(c, hipMemsetAsync(c->stat, 0, GSX_STAT_BYTES, c->stream));
     if (c->profiling) GSX_HIP(c, hipEventRecord(c->ev[EV_PROJ0], c->stream));
     hipLaunchKernelGGL(k_frame_init, dim3(gsx_div_up(n_tiles, 256)), dim3(256), 0, c->stream, c->ctl, c->m_dev, c->live_bits,
                        c->tile_state, vp.tiles_x, vp.tiles_y, c->aux);

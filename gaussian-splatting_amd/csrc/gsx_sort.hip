@@ -246,6 +246,27 @@ static int launch_sort_in(gsx_ctx* c, const GsxSortBuffers& sb) {
     const GsxRadixPlan plan = gsx_radix_plan(top_bits ? LOW_BITS : total_bits);
     const uint32_t wide_mask = top_bits ? ~((1u << LOW_BITS) - 1u) : 0u;
     if (top_bits) GSX_HIP(c, hipMemsetAsync(&c->flags->wide_m, 0, sizeof(uint32_t), c->stream));
+    // Profiling level 2 brackets ONE thing per sort with a pair of events from the ring, rotating sort by sort: the scatter
+    // launch of pass 0, 1, ..., and (slot GSX_SAMPLE_WHOLE) the whole of keys + sort, from before the key kernel to behind
+    // the last pass.
+    int sampled_pass = -1;
+    if (sb.with_events) {
+        if (c->prof_level == 2 && plan.n_passes > 0) {
+            const uint32_t turn = c->prof_frame % (static_cast<uint32_t>(plan.n_passes) + 1u);
+            sampled_pass = turn == static_cast<uint32_t>(plan.n_passes) ? GSX_SAMPLE_WHOLE : static_cast<int>(turn);
+        }
+        c->sampled_pass = sampled_pass;
+        ++c->prof_frame;
+    }
+    hipEvent_t samp0 = nullptr, samp1 = nullptr;
+    if (sampled_pass >= 0) {
+        const uint32_t slot = c->samp_pos++ % GSX_SAMPLE_RING;
+        gsx_sample_drain(c, slot);                  // (a slot comes round again 32 frames later: long finished)
+        c->samp_pass[slot] = sampled_pass;
+        samp0 = c->samp_ev[slot][0];
+        samp1 = c->samp_ev[slot][1];
+    }
+    if (sampled_pass == GSX_SAMPLE_WHOLE) GSX_HIP(c, hipEventRecord(samp0, c->stream));
     if (profiling) GSX_HIP(c, hipEventRecord(c->ev[EV_KEY0], c->stream));
     if (c->sel_iota)
         hipLaunchKernelGGL(k_keygen_hist0<true>, dim3(g), dim3(GSX_SORT_NT), 0, c->stream, c->pos4, nullptr, c->m_dev, c->cam[0],
@@ -257,19 +278,6 @@ static int launch_sort_in(gsx_ctx* c, const GsxSortBuffers& sb) {
                            c->flags);
     if (profiling) GSX_HIP(c, hipEventRecord(c->ev[EV_KEY1], c->stream));
     uint32_t cur = 0;
-    int sampled_pass = -1;
-    if (sb.with_events) {
-        sampled_pass = c->sampled_pass = (c->prof_level == 2 && plan.n_passes > 0) ? static_cast<int>(c->prof_frame % static_cast<uint32_t>(plan.n_passes)) : -1;
-        ++c->prof_frame;
-    }
-    hipEvent_t samp0 = nullptr, samp1 = nullptr;
-    if (sampled_pass >= 0) {
-        const uint32_t slot = c->samp_pos++ % GSX_SAMPLE_RING;
-        gsx_sample_drain(c, slot);                  // (a slot comes round again 32 frames later: long finished)
-        c->samp_pass[slot] = sampled_pass;
-        samp0 = c->samp_ev[slot][0];
-        samp1 = c->samp_ev[slot][1];
-    }
     uint32_t* result = sb.result;
     for (int p = 0; p < plan.n_passes; ++p) {
         const bool first = p == 0, last = p + 1 == plan.n_passes;
@@ -288,6 +296,7 @@ static int launch_sort_in(gsx_ctx* c, const GsxSortBuffers& sb) {
                                                           profiling ? c->ev[EV_X0 + 7] : nullptr);
         hipLaunchKernelGGL(k_copy_gated, dim3(g), dim3(512), 0, c->stream, &c->flags->wide_m, sb.vals[cur ^ 1], result);
     }
+    if (sampled_pass == GSX_SAMPLE_WHOLE) GSX_HIP(c, hipEventRecord(samp1, c->stream));
     if (profiling) GSX_HIP(c, hipEventRecord(c->ev[EV_SORT1], c->stream));
     GSX_HIP(c, hipGetLastError());
     if (sb.with_events) {   // (the context's own sort: what gsx_get_timings reports)
@@ -392,7 +401,6 @@ void gsx_sample_drain(gsx_ctx* c, uint32_t slot) {
     float ms = 0.0f;
     if (hipEventSynchronize(c->samp_ev[slot][1]) != hipSuccess) return;
     if (hipEventElapsedTime(&ms, c->samp_ev[slot][0], c->samp_ev[slot][1]) != hipSuccess) return;
-    if (p < 4) { c->samp_sum_ms[p] += ms; ++c->samp_n[p]; }
-    c->samp_last_ms = ms;
-    c->samp_last_pass = p;
+    if (p <= GSX_SAMPLE_WHOLE) { c->samp_sum_ms[p] += ms; ++c->samp_n[p]; }
+    if (p < GSX_SAMPLE_WHOLE) { c->samp_last_ms = ms; c->samp_last_pass = p; }
 }

@@ -3,8 +3,9 @@
 Two natural shardings, no data-path collective until the frames are finished:
   * camera views   : rank r renders views r, r + R, r + 2R, ...
   * tile-row bands : rank r renders rows [y0, y1) of one frame, band edges on tile rows
-The single exchange is the gather of RGBA8 pixels to rank 0 (torch.distributed: nccl = RCCL over
-xGMI on the GPU box, gloo in the CPU tests).
+The single exchange is the gather of RGBA8 pixels to rank 0.  On GPUs it goes through the library's own entry point
+(gsx_gather: grouped RCCL send / recv on the context's stream, GsxFrameGather / gather_bands_gsx below); the
+torch.distributed forms (gather_to_rank0, BatchedFrameGather) are the harness for the gloo CPU tests and the fallback.
 """
 TILE_H = 16
 
@@ -115,3 +116,74 @@ class BatchedFrameGather:
             return None
         fb = self.frame_bytes
         return [[t[s * fb:(s + 1) * fb] for s in range(self.batch_frames)] for t in self.recv[b]]
+
+
+def band_gather_plan(bands, width):
+    """(offsets, sizes) in bytes of every rank's band inside a width x height RGBA8 frame: the recv_offsets / recv_bytes
+    of gsx_gather, with which the bands land in place in rank 0's frame."""
+    row = width * 4
+    return [y0 * row for y0, _ in bands], [(y1 - y0) * row for y0, y1 in bands]
+
+
+def gather_bands_gsx(g, fb_ptr, bands, width, rank, root=0):
+    """Tile-band sharding, the exchange step: every rank has rendered rows [y0, y1) of the frame into ITS OWN full-size
+    framebuffer at fb_ptr (device pointer); the bands are gathered into the root's framebuffer in place (the root's own
+    band is already there).  Queued on the context's stream."""
+    off, size = band_gather_plan(bands, width)
+    g.gather(fb_ptr + off[rank], size[rank], fb_ptr if rank == root else None, off if rank == root else None,
+             size if rank == root else None, root)
+
+
+class GsxFrameGather:
+    """BatchedFrameGather on gsx_gather: every rank renders into the slots of a batch buffer, a full batch goes to rank 0
+    in one grouped RCCL exchange.  Everything (frames and gathers) is queued on the context's stream, so no host-side
+    or cross-stream waits exist: a batch buffer is re-used by frames queued BEHIND the gather that reads it.  Two batch
+    buffers alternate so that on rank 0 the batch received last stays readable while the next one is filled."""
+
+    def __init__(self, g, rank, world, frame_bytes, batch_frames, alloc):
+        """alloc(nbytes) -> (device pointer, keep-alive object)."""
+        self.g, self.rank, self.world = g, rank, world
+        self.frame_bytes, self.batch_frames = frame_bytes, batch_frames
+        nb = batch_frames * frame_bytes
+        self.keep = []
+        self.batches = []
+        for _ in range(2):
+            ptr, keep = alloc(nb)
+            self.batches.append(ptr)
+            self.keep.append(keep)
+        self.recv = [None, None]
+        if rank == 0:
+            for b in range(2):
+                ptr, keep = alloc(nb * world)
+                self.recv[b] = ptr
+                self.keep.append(keep)
+        self.filled = [0, 0]          # frames rendered into the batch since its last gather
+        self.gathers = 0
+
+    def slot(self, i):
+        b, s = (i // self.batch_frames) % 2, i % self.batch_frames
+        self.filled[b] = s + 1
+        return self.batches[b] + s * self.frame_bytes
+
+    def _start(self, b):
+        nb = self.batch_frames * self.frame_bytes
+        # whole batch buffers are exchanged (a partial last batch carries stale slots: sizes must agree on all ranks)
+        off = [r * nb for r in range(self.world)]
+        size = [nb] * self.world
+        root = self.rank == 0
+        self.g.gather(self.batches[b], nb, self.recv[b] if root else None, off if root else None, size if root else None, 0)
+        self.filled[b] = 0
+        self.gathers += 1
+
+    def frame_done(self, i):
+        if i % self.batch_frames == self.batch_frames - 1:
+            self._start((i // self.batch_frames) % 2)
+
+    def finish(self):
+        for b in range(2):
+            if self.filled[b]:
+                self._start(b)
+
+    def frame_on_rank0(self, b, r, s):
+        """rank 0: device pointer of slot s of rank r's batch b as received last."""
+        return self.recv[b] + (r * self.batch_frames + s) * self.frame_bytes

@@ -90,6 +90,8 @@ typedef struct gsx_timings {
     uint64_t tile_pairs;    /* (tile, splat) pairs the binner emitted (after occlusion culling) */
     uint32_t render_iters;  /* near -> far iterations of the frame that emitted pairs */
     uint32_t scatter_sample; /* profiling level 2: 1 + index of the radix pass whose scatter launch scatter_ms times; else 0 */
+    uint64_t raster_shades;  /* profiling level 1: (wave, splat) visits of the rasterizer's shading loop in the last frame */
+    uint64_t raster_blends;  /* profiling level 1: pixels blended (a visit blends up to 128 pixels) */
 } gsx_timings;
 
 /* ---- lifecycle (replaces Renderer::init device bring-up, renderer.cpp:3-100) ---- */
@@ -99,8 +101,8 @@ const char* gsx_last_error(const gsx_ctx* ctx);
 int gsx_sync(gsx_ctx* ctx);
 /* 0 = no events (default).  1 = HIP events around every stage and every radix scatter launch
  * (gsx_get_timings fills all *_ms fields; the ~20 events cost tens of microseconds per frame).
- * 2 = sampled: per frame only ONE k_radix_scatter launch of the depth sort is bracketed, the pass
- * rotating frame by frame (scatter_ms = the latest such launch, scatter_sample says which pass).
+ * 2 = sampled: per frame only ONE thing is bracketed, rotating frame by frame: the k_radix_scatter launch of pass 0, 1, ...
+ * of the depth sort (scatter_ms = the latest such launch, scatter_sample says which pass), then keys + sort as a whole.
  * The samples go through a ring of event pairs, so frames can be queued back to back without
  * reading anything in between; gsx_get_scatter_samples returns what has accumulated. */
 int gsx_set_profiling(gsx_ctx* ctx, int enabled);
@@ -109,6 +111,9 @@ int gsx_get_timings(gsx_ctx* ctx, gsx_timings* out);
  * duration (ms) and the number of sampled k_radix_scatter launches since the last reset.  Waits for the
  * queued work like gsx_get_timings; reset != 0 clears the sums. */
 int gsx_get_scatter_samples(gsx_ctx* ctx, double sum_ms[4], uint32_t launches[4], int reset);
+/* Profiling level 2 also brackets keys + sort AS A WHOLE (from before the key kernel to behind the last radix pass) in
+ * every (passes + 1)-th sort of the rotation: summed duration (ms) and number of such sorts since the last reset. */
+int gsx_get_sort_samples(gsx_ctx* ctx, double* sum_ms, uint32_t* sorts, int reset);
 /* Tuning knobs of the frame loop (no counterpart in the reference; 0 restores the default):
  *   "pair_budget"   (tile, splat) pairs one near -> far iteration may emit (sizes the pair buffers,
  *                   12 bytes per pair); the device cuts iterations to fit and a frame that needs
@@ -202,6 +207,28 @@ int gsx_set_framebuffer_dev(gsx_ctx* ctx, void* rgba8_dev, uint64_t capacity_byt
  * work or collectives against the frames (e.g. torch.cuda.ExternalStream + RCCL).  No reference counterpart:
  * the reference's queue is the wgpu::Queue handed to SplatMesh::initialize (SplatMesh.h:72). */
 int gsx_get_stream(gsx_ctx* ctx, void** hip_stream);
+
+/* ---- multi-GPU: the gather of finished pixels to one rank.  No counterpart in the reference,
+ * which is one process on one GPU.  One process and one context per GPU; the splat set is replicated; ranks render
+ * different camera views or different tile bands of one frame (gsx_render's y0/y1) and nothing is exchanged until
+ * the pixels are finished.  The exchange is RCCL point-to-point over xGMI: inside one group the root posts a receive
+ * per peer and every peer one send, so each transfer has its own link.  librccl is loaded on first use. ---- */
+typedef struct gsx_comm gsx_comm;
+#define GSX_COMM_ID_BYTES 128
+/* Rank 0 creates the id (ncclGetUniqueId) and hands it to the other ranks by whatever the host has (MPI, a file, a
+ * torch.distributed broadcast). */
+int gsx_comm_unique_id(void* id128_out);
+/* Collective over the nranks processes: returns when all have joined.  nranks == 1 needs no id and no RCCL. */
+int gsx_comm_init(gsx_ctx* ctx, const void* id128, int rank, int nranks, gsx_comm** out);
+int gsx_comm_destroy(gsx_comm* comm);
+/* Every rank contributes send_bytes bytes at send_dev; on `root`, rank r's bytes land at recv_dev + recv_offsets[r]
+ * (recv_bytes[r] of them; recv_bytes[r] must equal what rank r sends, recv_bytes[root] the root's own send_bytes).
+ * recv_* are read on the root only.  With offsets = y0 * width * 4 the bands of one frame are gathered straight into
+ * place; with offsets = r * frame_bytes * batch a batch of whole frames per rank.  Queued on the context's stream:
+ * ordered behind the frames already queued (a frame queued by gsx_render is completed first, which may wait for it on
+ * the host), complete after gsx_sync (or any stream wait) on the root. */
+int gsx_gather(gsx_ctx* ctx, gsx_comm* comm, const void* send_dev, uint64_t send_bytes, void* recv_dev,
+               const uint64_t* recv_offsets, const uint64_t* recv_bytes, int root);
 
 /* ---- host-only helpers (no GPU touched): the load-time half of ResourceManager and
  * the scene-graph math that produces the path's inputs. ---- */

@@ -69,6 +69,50 @@ if rank == 0:
         ok &= got1 == [int(frame(r, i)[0]) for i in (3, 4, 5)]
         got0 = [int(t[0]) for t in bg.frames_on_rank0(0)[r]]
         ok &= got0 == [int(frame(r, 6)[0]), int(frame(r, 1)[0]), int(frame(r, 2)[0])]
+# --- the gsx_gather forms (bench.py on GPUs): same argument contract as include/gsx.h gsx_gather, carried by gloo
+#     send / recv over a byte heap whose offsets stand in for device pointers ---
+class HeapGsx:
+    BASE = 4096
+    def __init__(self, nbytes):
+        self.heap = torch.zeros(nbytes, dtype=torch.uint8)
+        self.top = 0
+    def alloc(self, nbytes):
+        p = self.BASE + self.top
+        self.top += (nbytes + 255) // 256 * 256
+        assert self.top <= self.heap.numel()
+        return p, None
+    def mem(self, p, n):
+        return self.heap[p - self.BASE:p - self.BASE + n]
+    def gather(self, send_ptr, send_bytes, recv_ptr=None, recv_offsets=None, recv_bytes=None, root=0):
+        if rank == root:
+            assert recv_bytes[root] == send_bytes
+            if recv_ptr + recv_offsets[root] != send_ptr and send_bytes:
+                self.mem(recv_ptr + recv_offsets[root], send_bytes).copy_(self.mem(send_ptr, send_bytes).clone())
+            for r in range(world):
+                if r != root and recv_bytes[r]:
+                    dist.recv(self.mem(recv_ptr + recv_offsets[r], recv_bytes[r]), src=r)
+        elif send_bytes:
+            dist.send(self.mem(send_ptr, send_bytes).contiguous(), dst=root)
+hg = HeapGsx(1 << 20)
+# bands, gathered in place into rank 0's frame
+fb_ptr, _ = hg.alloc(W * H * 4)
+hg.mem(fb_ptr, W * H * 4).copy_(torch.from_numpy(render(2, y0, y1).reshape(-1).copy()))
+mg.gather_bands_gsx(hg, fb_ptr, bands, W, rank)
+if rank == 0:
+    ok &= bool(np.array_equal(hg.mem(fb_ptr, W * H * 4).numpy(), render(2).reshape(-1)))
+off, size = mg.band_gather_plan(bands, W)
+ok &= off[0] == 0 and sum(size) == W * H * 4 and all(o + s == o2 for o, s, o2 in zip(off, size, off[1:]))
+# view batches: 7 frames per rank in batches of 3
+fgx = mg.GsxFrameGather(hg, rank, world, FB, B, hg.alloc)
+for i in range(NF):
+    hg.mem(fgx.slot(i), FB).copy_(frame(rank, i))
+    fgx.frame_done(i)
+fgx.finish()
+ok &= fgx.gathers == 3
+if rank == 0:
+    for r in range(world):
+        ok &= [int(hg.mem(fgx.frame_on_rank0(1, r, s), FB)[0]) for s in range(B)] == [int(frame(r, i)[0]) for i in (3, 4, 5)]
+        ok &= [int(hg.mem(fgx.frame_on_rank0(0, r, s), FB)[0]) for s in range(B)] == [int(frame(r, i)[0]) for i in (6, 1, 2)]
     print("RESULT", "OK" if ok else "MISMATCH")
 dist.barrier()
 dist.destroy_process_group()

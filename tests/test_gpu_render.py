@@ -363,9 +363,12 @@ def test_frames_queued_back_to_back(gsx_fresh, pkg, oracle, synth):
     assert np.array_equal(gsx.render(unis[1], w, h), ref[1])
     assert np.array_equal(gsx.sort(cams[2][2]), perms[2])
     means, launches = gsx.scatter_samples()
-    assert sum(launches.values()) == 6 and all(v > 0.0 for v in means.values())
+    whole_ms, whole_n = gsx.sort_samples()
+    # six sorts were sampled: the rotation goes pass 0, 1, ..., then keys + sort as a whole
+    assert sum(launches.values()) + whole_n == 6 and whole_n >= 1 and all(v > 0.0 for v in means.values())
     passes = gsx.timings()["sort_passes"]
-    assert sorted(launches) == list(range(min(passes, 3)))   # the sampled pass rotates frame by frame over the ungated passes
+    assert set(launches) <= set(range(min(passes, 3))) and len(launches) >= 2
+    assert whole_ms > max(means.values())                    # the whole sort takes longer than any one of its launches
 
 
 def test_render_into_caller_owned_target(gsx_fresh, pkg, oracle, synth):

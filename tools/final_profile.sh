@@ -1,13 +1,13 @@
 #!/bin/bash
 # Round-end evidence: the default bench line, then the same command under rocprofv3 --kernel-trace --stats.
 set -e
-timeout -k 10 300 python bench.py > gpurun_out/r1_bench.json 2> gpurun_out/r1_bench.err
+timeout -k 10 300 python bench.py > gpurun_out/r2_bench.json 2> gpurun_out/r2_bench.err
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-rm -rf gpurun_out/prof_r1f
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_r1f -o r1f -- python3 bench.py --cpu-frames 0 > gpurun_out/r1_bench_under_rocprof.json 2> gpurun_out/r1_bench_under_rocprof.err
-python tools/kstats.py gpurun_out/prof_r1f > gpurun_out/r1_bench_kernel_stats.txt
-cp gpurun_out/prof_r1f/*/*kernel_stats.csv gpurun_out/r1_bench_kernel_stats.csv 2>/dev/null || cp gpurun_out/prof_r1f/*kernel_stats.csv gpurun_out/r1_bench_kernel_stats.csv
-python tools/ktrace.py gpurun_out/prof_r1f 48 0.5 > gpurun_out/r1_bench_kernel_trace_excerpt.txt
-cat gpurun_out/r1_bench_kernel_stats.txt
+rm -rf gpurun_out/prof_r2f
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_r2f -o r2f -- python3 bench.py --cpu-frames 0 > gpurun_out/r2_bench_under_rocprof.json 2> gpurun_out/r2_bench_under_rocprof.err
+python tools/kstats.py gpurun_out/prof_r2f > gpurun_out/r2_bench_kernel_stats.txt
+cp gpurun_out/prof_r2f/*/*kernel_stats.csv gpurun_out/r2_bench_kernel_stats.csv 2>/dev/null || cp gpurun_out/prof_r2f/*kernel_stats.csv gpurun_out/r2_bench_kernel_stats.csv
+python tools/ktrace.py gpurun_out/prof_r2f 48 0.5 > gpurun_out/r2_bench_kernel_trace_excerpt.txt
+cat gpurun_out/r2_bench_kernel_stats.txt
 python -c "
-import json; d=json.load(open('gpurun_out/r1_bench.json')); print(d['ms_per_step'], d['value'], d['roofline']['frac'], d['cpu_baseline'])"
+import json; d=json.load(open('gpurun_out/r2_bench.json')); print(d['ms_per_step'], d['value'], d['roofline']['frac'], d['cpu_baseline'])"

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""tools/pmc_traffic.py <dir made by tools/pmc_traffic.sh> [splats] -> profiles/r1_scatter_traffic.json
+"""tools/pmc_traffic.py <dir made by tools/pmc_traffic.sh> [splats] -> profiles/r2_scatter_traffic.json
 
 Per-launch HBM traffic of k_radix_scatter<u32> from rocprofv3 PMC passes.  FETCH_SIZE / WRITE_SIZE are scaled by
 factors calibrated on a streaming copy with the kernel's own access width (4 bytes per lane) and a known byte count."""
@@ -31,10 +31,10 @@ for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
                             "bytes_per_unit_at_16B_per_lane": cal_bytes / raw16, "bytes_per_launch": raw * scale4}
     total += raw * scale4
 res["hbm_bytes_per_launch"] = total
-res["algorithmic_bytes_per_launch"] = 16 * n
+res["algorithmic_bytes_per_launch"] = (12 + 16 + 16) / 3 * n      # pass 0 generates the index (12 B per key), passes 1, 2 move key + index (16 B)
 res["note"] = ("k_radix_scatter<u32>, mean over the three passes of the depth sort; FETCH_SIZE and WRITE_SIZE from separate "
-               "rocprofv3 --pmc passes of `bench.py --steps 6 --warmup 2`, each scaled by the factor a 96 MiB 4-byte-per-lane "
+               "rocprofv3 --pmc passes of `bench.py --steps 6 --warmup 2 --cpu-frames 0 --no-extras`, each scaled by the factor a 96 MiB 4-byte-per-lane "
                "streaming copy (tools/membw.hip k_copy4) gives for that counter")
 os.makedirs("profiles", exist_ok=True)
-json.dump(res, open("profiles/r1_scatter_traffic.json", "w"), indent=1)
+json.dump(res, open("profiles/r2_scatter_traffic.json", "w"), indent=1)
 print(json.dumps(res, indent=1))
