@@ -6,6 +6,7 @@ The image oracle is our restatement; the reference's WebGPU render is unpinned."
 import numpy as np
 import pytest
 
+import known_answers as ka
 import orc
 
 pytestmark = pytest.mark.gpu
@@ -113,9 +114,16 @@ def test_render_bayer_and_threshold_modes(gsx, pkg, oracle, synth, bayer, scale)
     perm = gsx.sort(cam)
     img = gsx.render(pkg.make_uniforms(proj, view, bayerSize=bayer, bayerScale=scale), w, h)
     ref = oracle.render(splats, perm, orc.make_uniforms(proj, view, bayerSize=bayer, bayerScale=scale), w, h)
-    # hard 0/1 alpha: a pixel whose alpha sits on the threshold may flip; require 99.5 % exact pixels
-    same = np.all(img == ref, axis=-1).mean()
-    assert same >= 0.995, same
+    # hard 0/1 alpha: the only pixels that may differ are those where some fragment's alpha sits ON the threshold, i.e. pixels
+    # whose ORACLE value changes when bayerScale moves by 2e-4 relative (the two programs round alpha differently in the
+    # last bits); every other pixel must agree exactly
+    stable = np.ones((h, w), bool)
+    for eps in (-2e-4, 2e-4):
+        moved = oracle.render(splats, perm, orc.make_uniforms(proj, view, bayerSize=bayer, bayerScale=scale * (1.0 + eps)), w, h)
+        stable &= np.all(moved == ref, axis=-1)
+    assert stable.mean() >= 0.97, stable.mean()
+    assert np.array_equal(img[stable], ref[stable]), int(np.any(img != ref, axis=-1)[stable].sum())
+    assert np.all(img == ref, axis=-1).mean() >= 0.995
 
 
 def test_render_rejects_bad_arguments(gsx, pkg, oracle, synth):
@@ -149,6 +157,123 @@ def test_render_repeated_frames_on_one_context(gsx, pkg, oracle, synth):
                 check_image(img, oracle.render(splats, perm, orc.make_uniforms(proj, view), w, h))
                 first[steps] = img.copy()
             assert np.array_equal(img, first[steps]), f"frame changed on round {rnd}"
+
+
+def _ka_render(gsx, pkg, splats, order, **kw):
+    """Draw `splats` in exactly `order` (far -> near) through the C ABI: the permutation comes from gsx_sort, so the scenes
+    below are laid out with distinct distances and the sort's result is asserted to BE that order."""
+    view, proj = ka.matrices()
+    gsx.upload(np.ascontiguousarray(splats))
+    perm = gsx.sort(np.array([0.0, 0.0, 5.0], np.float32))
+    assert np.array_equal(perm, np.asarray(order, np.uint32))
+    return gsx.render(pkg.make_uniforms(proj, view, **kw), ka.W, ka.H)
+
+
+def _ka_check(img, want):
+    """GPU frame against a closed-form frame: within 1/255 everywhere (the GPU composites front to back, the closed form
+    back to front), byte-exact away from 8-bit rounding boundaries."""
+    got = img[..., :3].astype(np.int32)
+    exp = ka.to_rgba8(want).astype(np.int32)
+    assert np.abs(got - exp).max() <= 1
+    ok = ~ka.near_rounding_boundary(want, margin=0.2)
+    assert np.array_equal(got[ok], exp[ok])
+    assert np.all(img[..., 3] == 255)
+
+
+def test_known_answers_isotropic_and_blend_order(gsx, pkg):
+    # tests/known_answers.py: hand-derived pixels (the same vectors pin the oracle in tests/test_oracle_known_answers.py)
+    s = ka.splat((0, 0, 0), np.eye(3) * 0.01, (0.9, 0.4, 0.1, 0.8))[None]
+    img = _ka_render(gsx, pkg, s, [0])
+    assert tuple(img[50, 50]) == (176, 80, 22, 255) and tuple(img[50, 43]) == (14, 13, 13, 255) and tuple(img[52, 49]) == (90, 44, 17, 255)
+    assert tuple(img[50, 42]) == (13, 13, 13, 255)                          # one pixel past the cutOff edge: clear colour
+    _ka_check(img, ka.expected_image([((0, 0, 0), 0.1, 0.1, 0.0, (0.9, 0.4, 0.1, 0.8))]))
+    far = ka.splat((0, 0, 0), np.eye(3) * 0.01, (0.1, 0.8, 0.3, 0.7))
+    near = ka.splat((0, 0, 1), np.eye(3) * 0.01, (0.9, 0.2, 0.6, 0.5))
+    img = _ka_render(gsx, pkg, np.stack([far, near]), [0, 1])               # camera at z = 5: index 0 is farther, drawn first
+    assert tuple(img[50, 50]) == (121, 96, 102, 255)
+    img = _ka_render(gsx, pkg, np.stack([near, far]), [1, 0])               # same scene, splats stored the other way round
+    assert tuple(img[50, 50]) == (121, 96, 102, 255)
+    _ka_check(img, ka.expected_image([((0, 0, 0), 0.1, 0.1, 0.0, (0.1, 0.8, 0.3, 0.7)), ((0, 0, 1), 0.1, 0.1, 0.0, (0.9, 0.2, 0.6, 0.5))]))
+    # the colours swapped between the depths: what the OTHER draw order of the first scene would give
+    far2 = ka.splat((0, 0, 0), np.eye(3) * 0.01, (0.9, 0.2, 0.6, 0.5))
+    near2 = ka.splat((0, 0, 1), np.eye(3) * 0.01, (0.1, 0.8, 0.3, 0.7))
+    img = _ka_render(gsx, pkg, np.stack([far2, near2]), [0, 1])
+    _ka_check(img, ka.expected_image([((0, 0, 0), 0.1, 0.1, 0.0, (0.9, 0.2, 0.6, 0.5)), ((0, 0, 1), 0.1, 0.1, 0.0, (0.1, 0.8, 0.3, 0.7))]))
+
+
+@pytest.mark.parametrize("phi", [30.0, -20.0, 75.0])
+def test_known_answers_rotated_anisotropic(gsx, pkg, phi):
+    rgba = (0.2, 0.6, 1.0, 0.9)
+    s = ka.splat((0.2, -0.1, 0.5), ka.cov_xy(0.2, 0.05, 0.1, phi), rgba)[None]
+    _ka_check(_ka_render(gsx, pkg, s, [0]), ka.expected_image([((0.2, -0.1, 0.5), 0.2, 0.05, phi, rgba)]))
+
+
+def test_known_answers_threshold_and_bayer_permutations(gsx, pkg):
+    s = ka.splat((0, 0, 0), np.eye(3) * 0.01, (0.3, 0.9, 0.5, 1.0))[None]
+    img = _ka_render(gsx, pkg, s, [0], bayerSize=10, bayerScale=0.5)
+    want = ka.expected_image([((0, 0, 0), 0.1, 0.1, 0.0, (0.3, 0.9, 0.5, 1.0))], mode="threshold", bayer_scale=0.5)
+    assert np.array_equal(img[..., :3], ka.to_rgba8(want))
+    # per-instance Bayer permutation (bayerSize 2): `state` clipped splats occupy the first draw ranks.  They sit BEHIND the
+    # camera at growing distance so that the sort puts them first (farthest), in index order reversed.
+    flat = lambda opacity: ka.splat((0, 0, 0), np.eye(3) * 4.0, (1.0, 1.0, 1.0, opacity))
+    for state in sorted(ka.PERMUTATIONS):
+        drawn = np.zeros((4, 4), np.int32)
+        culled = [ka.splat((0.0, 0.0, 12.0 + k), np.eye(3) * 0.01, (1, 1, 1, 1)) for k in range(state)]   # distance 7 + k > 5
+        for opacity in (0.3, 0.5, 0.7, 0.9):
+            s = np.stack(culled + [flat(opacity)])
+            img = _ka_render(gsx, pkg, s, list(range(state - 1, -1, -1)) + [state], bayerSize=2)
+            block = img[48:52, 48:52, 0]
+            assert set(np.unique(block)) <= {13, 255}
+            drawn += (block == 255)
+        value = 4 - drawn
+        arr = ka.PERMUTATIONS[state]
+        for y in range(4):
+            for x in range(4):
+                assert value[y, x] == arr[(x % 2) * 2 + (y % 2)], (state, x, y)
+    # bayerSize 4, state 0: value = 16 - number of the 16 frames (opacity (k + 0.5) / 17) in which the pixel survives
+    drawn = np.zeros((4, 4), np.int32)
+    for k in range(1, 17):
+        img = _ka_render(gsx, pkg, flat((k + 0.5) / 17.0)[None], [0], bayerSize=4)
+        drawn += (img[48:52, 48:52, 0] == 255)
+    for x in range(4):
+        for y in range(4):
+            assert 16 - drawn[y, x] == ka.BAYER4_STATE0[x][y], (x, y)
+
+
+def test_dense_scene_default_schedule_matches_oracle(gsx_fresh, pkg, oracle, synth):
+    """The headline code path — DEFAULT options, history-driven schedule, several iterations, tiles retiring, per-pixel
+    freeze — against the image oracle: 420 k opaque-ish splats at 640x360 (first window 256 K ranks, so the frame
+    takes at least two iterations; the oracle needs a few seconds)."""
+    gsx = gsx_fresh
+    w, h, n = 640, 360, 420_000
+    splats = oracle.raw_to_splat(synth.clustered_cloud(n, seed=17, n_clusters=6, sigma=0.5, frac=0.8, centre_extent=1.0, scale_mul=1.5))
+    view, proj, cam = camera(oracle, w, h, steps=1)
+    u = pkg.make_uniforms(proj, view)
+    gsx.upload(splats)
+    perm = gsx.sort(cam)
+    ref = oracle.render(splats, perm, orc.make_uniforms(proj, view), w, h)
+    assert ref[..., :3].std() > 5
+    frames = []
+    for k in range(4):                                   # frame 0 has no history; 1 .. 3 run the history-driven schedule
+        frames.append(gsx.render(u, w, h).copy())
+        t = gsx.timings()
+        if k == 0:
+            assert t["render_iters"] >= 2, t
+            assert t["tile_pairs"] > 1_000_000
+    check_image(frames[0], ref)
+    for f in frames[1:]:
+        assert np.array_equal(f, frames[0])
+    # a second pose on the same context (the schedule now carries the first pose's history)
+    view2, proj2, cam2 = camera(oracle, w, h, steps=7)
+    perm2 = gsx.sort(cam2)
+    img2 = gsx.render(pkg.make_uniforms(proj2, view2), w, h)
+    pairs_default = gsx.timings()["tile_pairs"]
+    check_image(img2, oracle.render(splats, perm2, orc.make_uniforms(proj2, view2), w, h))
+    # tiles did retire: binning everything in one shot emits more pairs, and the same bytes
+    gsx.set_option("chunk_first", 1 << 30)
+    one = gsx.render(pkg.make_uniforms(proj2, view2), w, h)
+    assert gsx.timings()["tile_pairs"] > pairs_default
+    assert np.array_equal(one, img2)
 
 
 def dense_scene(oracle, synth, n, seed):
