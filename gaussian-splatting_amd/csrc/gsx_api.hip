@@ -131,7 +131,7 @@ int gsx_destroy(gsx_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     dev_free(&c->pos4); dev_free(&c->geo);
     dev_free(&c->sel_idx); dev_free(&c->m_dev);
-    dev_free(&c->lod_a); dev_free(&c->lod_b); dev_free(&c->lod_parent); dev_free(&c->lod_leaf);
+    dev_free(&c->lod_a); dev_free(&c->lod_b); dev_free(&c->lod_parent); dev_free(&c->lod_leaf); dev_free(&c->lod_child); dev_free(&c->lod_queue[0]); dev_free(&c->lod_queue[1]); dev_free(&c->lod_qcount); dev_free(&c->lod_top_anc);
     dev_free(&c->lod_stop); dev_free(&c->lod_emit); dev_free(&c->lod_block_sums);
     for (int b = 0; b < 2; ++b) { dev_free(&c->keys[b]); dev_free(&c->vals[b]); dev_free(&c->perm[b]); dev_free(&c->pair_key[b]); dev_free(&c->pair_val[b]); }
     dev_free(&c->sort_ws); dev_free(&c->aabb_dev); dev_free(&c->flags); dev_free(&c->pair_ws);
@@ -173,6 +173,8 @@ int gsx_set_option(gsx_ctx* c, const char* name, uint64_t value) {
         c->opt_chunk_growth = value;
     } else if (!std::strcmp(name, "no_history")) {
         c->opt_no_history = value ? 1 : 0;
+    } else if (!std::strcmp(name, "lod_walk")) {
+        c->opt_lod_walk = value ? 1 : 0;
     } else {
         c->err = std::string("unknown option: ") + name;
         return GSX_E_INVALID;
@@ -367,6 +369,55 @@ int gsx_set_lod_octree(gsx_ctx* c, const gsx_octree_flat* t) {
     GSX_HIP(c, hipMemcpy(c->lod_leaf, t->is_leaf, n, hipMemcpyHostToDevice));
     c->lod_kind = 1;
     c->lod_nodes = n;
+    // Levels of a BFS-ordered tree are contiguous id ranges and parent[] is non-decreasing: find the ranges.  A tree that is
+    // not laid out that way (or deeper than GSX_LOD_MAX_LEVELS) is still cut correctly, by the ancestor-walk kernels.
+    c->lod_levels = 0;
+    c->lod_top_levels = 0;
+    if (n > 0 && t->parent[0] == 0xFFFFFFFFu) {
+        uint32_t levels = 1, s = 0, e = 1;
+        c->lod_level_start[0] = 0;
+        c->lod_level_start[1] = 1;
+        bool bfs = true;
+        while (e < n && bfs) {
+            uint32_t j = e, last = s;
+            while (j < n && t->parent[j] != 0xFFFFFFFFu && t->parent[j] >= last && t->parent[j] < e) { last = t->parent[j]; ++j; }
+            if (j == e || levels == GSX_LOD_MAX_LEVELS) { bfs = false; break; }
+            s = e; e = j;
+            c->lod_level_start[++levels] = j;
+        }
+        // children of a node are contiguous in BFS order: (first child << 4) | count; at most 15 children, 2^28 nodes
+        std::vector<uint32_t> cw;
+        if (bfs && n < (1u << 28)) {
+            cw.assign(n, 0u);
+            for (uint32_t i = 1; i < n && bfs; ++i) {
+                uint32_t& w = cw[t->parent[i]];
+                if ((w & 15u) == 0u) w = i << 4;
+                if ((w & 15u) == 15u || (w >> 4) + (w & 15u) != i) bfs = false; else ++w;
+            }
+        } else {
+            bfs = false;
+        }
+        if (bfs) {
+            if ((rc = dev_alloc(c, &c->lod_child, n)) || (rc = dev_alloc(c, &c->lod_queue[0], n)) || (rc = dev_alloc(c, &c->lod_queue[1], n)) ||
+                (rc = dev_alloc(c, &c->lod_qcount, GSX_LOD_MAX_LEVELS + 2)))
+                return rc;
+            GSX_HIP(c, hipMemcpy(c->lod_child, cw.data(), static_cast<uint64_t>(n) * 4, hipMemcpyHostToDevice));
+            GSX_HIP(c, hipMemset(c->lod_qcount, 0, (GSX_LOD_MAX_LEVELS + 2) * sizeof(uint32_t)));
+            c->lod_levels = levels;
+            c->lod_top_levels = 1;       // (level 0 is the root alone); at most 8 levels: a top node and its ancestors fill 8 slots
+            while (c->lod_top_levels < levels && c->lod_top_levels < 8u && c->lod_level_start[c->lod_top_levels + 1] <= GSX_LOD_TOP_NODES)
+                ++c->lod_top_levels;
+            const uint32_t top_end = c->lod_level_start[c->lod_top_levels];
+            std::vector<uint32_t> anc(static_cast<size_t>(top_end) * 8u, 0xFFFFFFFFu);
+            for (uint32_t i = 0; i < top_end; ++i) {
+                uint32_t k = 0;
+                for (uint32_t p = i; p != 0xFFFFFFFFu && k < 8u; p = t->parent[p]) anc[i * 8u + k++] = p;
+            }
+            if ((rc = dev_alloc(c, &c->lod_top_anc, static_cast<uint64_t>(top_end) * 8u))) return rc;
+            GSX_HIP(c, hipMemcpy(c->lod_top_anc, anc.data(), anc.size() * 4, hipMemcpyHostToDevice));
+        }
+    }
+    c->lod_stamp = 255;
     return GSX_OK;
 }
 

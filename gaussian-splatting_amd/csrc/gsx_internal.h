@@ -10,7 +10,9 @@
 
 #define GSX_WAVE 64
 #define GSX_SAMPLE_RING 32
-#define GSX_SAMPLE_WHOLE 4     // sample slot of "keys + sort as a whole" (slots 0..3: the scatter launch of a radix pass)
+#define GSX_SAMPLE_WHOLE 4
+#define GSX_LOD_MAX_LEVELS 48
+#define GSX_LOD_TOP_NODES 4096u      // nodes of the leading octree levels one workgroup walks in LDS     // sample slot of "keys + sort as a whole" (slots 0..3: the scatter launch of a radix pass)
 #define GSX_STAT_BYTES (64 * 16 * 8)   // rasterizer counters (profiling level 1): 64 shards x one 128-byte line of u64 words
 #define GSX_AUX_OFFSET 512   // bytes from the frame control block to the aux words (same allocation)
 
@@ -131,6 +133,15 @@ struct gsx_ctx {
     uint8_t* lod_emit = nullptr;
     uint32_t* lod_block_sums = nullptr;
     uint64_t lod_cap = 0;
+    // octree in BFS order (levels are contiguous id ranges): the cut is evaluated top-down, level by level (gsx_lod.hip)
+    uint32_t lod_levels = 0;                            // 0 = not BFS-shaped: the general ancestor-walk kernels are used
+    uint32_t lod_top_levels = 0;                        // leading levels small enough for the one-workgroup kernel
+    uint32_t lod_level_start[GSX_LOD_MAX_LEVELS + 1] = {};
+    uint32_t* lod_child = nullptr;                      // (first child id << 4) | number of children, per node
+    uint32_t lod_stamp = 255;                           // frame stamp in the emit bytes (255 = clear them first)
+    uint32_t* lod_queue[2] = {nullptr, nullptr};        // per-level worklists (ping-pong), lod_nodes ids each
+    uint32_t* lod_qcount = nullptr;                     // queue length per level (zeroed by the compaction's scan kernel after every cut)
+    uint32_t* lod_top_anc = nullptr;                    // 8 ids per top node: itself and its ancestors (UINT32_MAX = none)
 
     // sort
     uint32_t* keys[2] = {nullptr, nullptr};
@@ -202,7 +213,7 @@ struct gsx_ctx {
     hipEvent_t frame_ev = nullptr;
     bool frame_pending = false;
     // tuning (gsx_set_option); 0 = automatic
-    uint64_t opt_pair_budget = 0, opt_chunk_first = 0, opt_chunk_growth = 0, opt_no_history = 0;
+    uint64_t opt_pair_budget = 0, opt_chunk_first = 0, opt_chunk_growth = 0, opt_no_history = 0, opt_lod_walk = 0;
 
     // timing
     hipEvent_t ev[40] = {};

@@ -72,6 +72,87 @@ __global__ __launch_bounds__(256) void k_hc_stop(const float4* __restrict__ ew, 
     stop[i] = (metric < thr || leaf[i]) ? 1 : 0;  // HC.cpp:120
 }
 
+// ---- octree in BFS order: top-down, level by level -------------------------------------------------------------
+// The reference's breadth-first walk only ever LOOKS at a node whose ancestors all failed the stop test.  The stop test
+// is the expensive part (8 corners x 3 matrix rows and 16 IEEE divisions: ~430 instructions per node), so evaluating all
+// 8.5 M nodes of cfg 3's tree and then walking ancestor chains is VALU-bound at 6x the necessary work (a cut of 1.1 M
+// nodes looks at 1.4 M).  In BFS order the children of a node are contiguous ids, so the walk is done as the reference
+// does it, with a queue per level: a looked-at node either stops (its emit byte gets the frame's stamp) or appends its
+// children to the next level's queue (one atomic per wave).  Queues are dense, so every lane of a wave evaluates a node
+// that needs it, and nothing is ever read for a node that is not reached.  The leading levels (<= 4096 nodes) are
+// handled by ONE workgroup: it evaluates all of them at once (no dependence between levels there) and then resolves
+// reachability in LDS, so a frame pays one launch and one memory round trip for them instead of five.
+// emit bytes carry a frame stamp (1..255) and compaction matches it, so the array is cleared every 255 cuts, not per cut.
+__device__ __forceinline__ bool gsx_octree_node_stops(const float4* __restrict__ a, const float4* __restrict__ b,
+                                                      const uint8_t* __restrict__ leaf, uint32_t i, const GsxMat4& vp, float thr) {
+    const float4 ca = a[i], cb = b[i];
+    const float area = gsx_screen_area(ca.x, ca.y, ca.z, ca.w, cb.x, cb.y, vp);
+    return leaf[i] || (area < thr);   // Octree.cpp:203
+}
+
+struct GsxLodLevels { uint32_t start[GSX_LOD_MAX_LEVELS + 1]; };
+
+// Leading levels (<= GSX_LOD_TOP_NODES nodes, <= 8 levels) in ONE launch without any dependence between threads: eight
+// adjacent lanes serve one top node and test the node itself (slot 0) and each of its ancestors (slots 1..7, ids from a
+// table built at set-up) at the same time - redundant work (every ancestor is tested once per descendant), but the whole
+// top of the tree costs one memory round trip and one stop test instead of one of each per level.  A node whose ancestors
+// all fail the test is reached: it is emitted if it stops, and in the last top level it queues its children otherwise.
+#define GSX_TOP_NT 256
+__global__ __launch_bounds__(GSX_TOP_NT) void k_octree_top(const float4* __restrict__ a, const float4* __restrict__ b,
+                                                           const uint8_t* __restrict__ leaf, const uint32_t* __restrict__ child,
+                                                           const uint32_t* __restrict__ top_anc, uint32_t top_end, uint32_t last_begin,
+                                                           uint32_t top_levels, GsxMat4 vp, float thr, uint8_t stamp,
+                                                           uint8_t* __restrict__ emit, uint32_t* __restrict__ queue_out,
+                                                           uint32_t* __restrict__ qcount) {
+    __shared__ uint32_t s_tmp[GSX_TOP_NT / 64];
+    __shared__ uint32_t s_base;
+    const uint32_t gid = blockIdx.x * GSX_TOP_NT + threadIdx.x, node = gid >> 3, slot = gid & 7u, lane = threadIdx.x & 63u;
+    const uint32_t id = node < top_end ? top_anc[gid] : 0xFFFFFFFFu;
+    const bool stops = id != 0xFFFFFFFFu && gsx_octree_node_stops(a, b, leaf, id, vp, thr);
+    const uint32_t group = static_cast<uint32_t>(__builtin_amdgcn_ballot_w64(stops) >> (lane & ~7u)) & 0xFFu;   // bit s = slot s stops
+    uint32_t fc = 0, nc = 0;
+    if (slot == 0u && node < top_end && (group & 0xFEu) == 0u) {       // reached: no ancestor stops
+        if (group & 1u) emit[node] = stamp;
+        else if (node >= last_begin) { const uint32_t cw = child[node]; fc = cw >> 4; nc = cw & 15u; }
+    }
+    uint32_t total;
+    const uint32_t excl = gsx_block_excl_scan<GSX_TOP_NT>(nc, s_tmp, &total);
+    if (total == 0u) return;                            // (uniform)
+    if (threadIdx.x == 0) s_base = atomicAdd(&qcount[top_levels], total);
+    __syncthreads();
+    const uint32_t base = s_base + excl;
+    for (uint32_t k = 0; k < nc; ++k) queue_out[base + k] = fc + k;
+}
+
+// One level: thread t looks at node queue_in[t].  NT = 256 for narrow levels (more CUs busy), 1024 for wide ones (one slot
+// reservation - a same-address atomic, ~10 ns each at the L2 - per 1024 nodes).
+template <int NT>
+__global__ __launch_bounds__(NT) void k_octree_level(const float4* __restrict__ a, const float4* __restrict__ b,
+                                                     const uint8_t* __restrict__ leaf, const uint32_t* __restrict__ child,
+                                                     uint32_t level, GsxMat4 vp, float thr, uint8_t stamp,
+                                                     uint8_t* __restrict__ emit, const uint32_t* __restrict__ queue_in,
+                                                     uint32_t* __restrict__ queue_out, uint32_t* __restrict__ qcount) {
+    __shared__ uint32_t s_tmp[NT / 64];
+    __shared__ uint32_t s_base;
+    const uint32_t cnt = qcount[level];
+    if (blockIdx.x * NT >= cnt) return;                 // the whole workgroup is past the queue
+    const uint32_t t = blockIdx.x * NT + threadIdx.x;
+    uint32_t fc = 0, nc = 0;
+    if (t < cnt) {
+        const uint32_t i = queue_in[t];
+        const uint32_t cw = child[i];
+        if (gsx_octree_node_stops(a, b, leaf, i, vp, thr)) emit[i] = stamp;
+        else { fc = cw >> 4; nc = cw & 15u; }
+    }
+    uint32_t total;
+    const uint32_t excl = gsx_block_excl_scan<NT>(nc, s_tmp, &total);
+    if (total == 0u) return;                            // (uniform)
+    if (threadIdx.x == 0) s_base = atomicAdd(&qcount[level + 1], total);
+    __syncthreads();
+    const uint32_t base = s_base + excl;
+    for (uint32_t k = 0; k < nc; ++k) queue_out[base + k] = fc + k;
+}
+
 // emit[i] = stop[i] && no ancestor stops.  Chains are as deep as the tree; most
 // walks end after a step or two because an ancestor near the cut stops.
 __global__ __launch_bounds__(256) void k_emit_flags(const uint8_t* __restrict__ stop, const uint32_t* __restrict__ parent,
@@ -92,7 +173,7 @@ __global__ __launch_bounds__(256) void k_emit_flags(const uint8_t* __restrict__ 
 #define GSX_CMP_IPT 16
 #define GSX_CMP_TILE (GSX_CMP_NT * GSX_CMP_IPT)
 
-__device__ __forceinline__ uint32_t gsx_load_flags16(const uint8_t* flags, uint32_t base, uint32_t n, uint32_t w[4]) {
+__device__ __forceinline__ uint32_t gsx_load_flags16(const uint8_t* flags, uint32_t base, uint32_t n, uint32_t match, uint32_t w[4]) {
     // 16 flag bytes per thread; flags buffers are padded to a multiple of 16 bytes
     uint32_t cnt = 0;
     if (base < n) {
@@ -100,7 +181,7 @@ __device__ __forceinline__ uint32_t gsx_load_flags16(const uint8_t* flags, uint3
         w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
-            const bool on = ((w[j >> 2] >> (8 * (j & 3))) & 0xFFu) != 0 && (base + j) < n;
+            const bool on = ((w[j >> 2] >> (8 * (j & 3))) & 0xFFu) == match && (base + j) < n;
             cnt += on ? 1u : 0u;
         }
     } else {
@@ -109,12 +190,12 @@ __device__ __forceinline__ uint32_t gsx_load_flags16(const uint8_t* flags, uint3
     return cnt;
 }
 
-__global__ __launch_bounds__(GSX_CMP_NT) void k_compact_count(const uint8_t* __restrict__ flags, uint32_t n,
+__global__ __launch_bounds__(GSX_CMP_NT) void k_compact_count(const uint8_t* __restrict__ flags, uint32_t n, uint32_t match,
                                                               uint32_t* __restrict__ block_sums) {
     __shared__ uint32_t s_tmp[GSX_CMP_NT / 64];
     uint32_t w[4];
     const uint32_t base = blockIdx.x * GSX_CMP_TILE + threadIdx.x * GSX_CMP_IPT;
-    const uint32_t cnt = gsx_load_flags16(flags, base, n, w);
+    const uint32_t cnt = gsx_load_flags16(flags, base, n, match, w);
     uint32_t total;
     gsx_block_excl_scan<GSX_CMP_NT>(cnt, s_tmp, &total);
     if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
@@ -122,7 +203,8 @@ __global__ __launch_bounds__(GSX_CMP_NT) void k_compact_count(const uint8_t* __r
 
 // single block: in-place exclusive scan of block_sums[0..nb), total -> *m_out
 __global__ __launch_bounds__(1024) void k_scan_block_sums(uint32_t* __restrict__ block_sums, uint32_t nb,
-                                                          uint32_t* __restrict__ m_out) {
+                                                          uint32_t* __restrict__ m_out, uint32_t* __restrict__ qcount) {
+    if (qcount && threadIdx.x <= GSX_LOD_MAX_LEVELS + 1) qcount[threadIdx.x] = 0u;   // the octree cut's level counters, for the next cut
     __shared__ uint32_t s_tmp[1024 / 64];
     __shared__ uint32_t s_carry;
     if (threadIdx.x == 0) s_carry = 0;
@@ -141,27 +223,28 @@ __global__ __launch_bounds__(1024) void k_scan_block_sums(uint32_t* __restrict__
     if (threadIdx.x == 0) *m_out = s_carry;
 }
 
-__global__ __launch_bounds__(GSX_CMP_NT) void k_compact_write(const uint8_t* __restrict__ flags, uint32_t n,
+__global__ __launch_bounds__(GSX_CMP_NT) void k_compact_write(const uint8_t* __restrict__ flags, uint32_t n, uint32_t match,
                                                               const uint32_t* __restrict__ block_offs,
                                                               uint32_t* __restrict__ out) {
     __shared__ uint32_t s_tmp[GSX_CMP_NT / 64];
     uint32_t w[4];
     const uint32_t base = blockIdx.x * GSX_CMP_TILE + threadIdx.x * GSX_CMP_IPT;
-    const uint32_t cnt = gsx_load_flags16(flags, base, n, w);
+    const uint32_t cnt = gsx_load_flags16(flags, base, n, match, w);
     uint32_t pos = block_offs[blockIdx.x] + gsx_block_excl_scan<GSX_CMP_NT>(cnt, s_tmp, nullptr);
     if (cnt == 0) return;
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
-        const bool on = ((w[j >> 2] >> (8 * (j & 3))) & 0xFFu) != 0 && (base + j) < n;
+        const bool on = ((w[j >> 2] >> (8 * (j & 3))) & 0xFFu) == match && (base + j) < n;
         if (on) out[pos++] = base + j;
     }
 }
 
-static int compact(gsx_ctx* c, uint32_t n) {
+// ids whose flag byte equals `match`, ascending
+static int compact(gsx_ctx* c, uint32_t n, uint32_t match = 1u) {
     const uint32_t nb = gsx_div_up(n, GSX_CMP_TILE);
-    hipLaunchKernelGGL(k_compact_count, dim3(nb), dim3(GSX_CMP_NT), 0, c->stream, c->lod_emit, n, c->lod_block_sums);
-    hipLaunchKernelGGL(k_scan_block_sums, dim3(1), dim3(1024), 0, c->stream, c->lod_block_sums, nb, c->m_dev);
-    hipLaunchKernelGGL(k_compact_write, dim3(nb), dim3(GSX_CMP_NT), 0, c->stream, c->lod_emit, n, c->lod_block_sums,
+    hipLaunchKernelGGL(k_compact_count, dim3(nb), dim3(GSX_CMP_NT), 0, c->stream, c->lod_emit, n, match, c->lod_block_sums);
+    hipLaunchKernelGGL(k_scan_block_sums, dim3(1), dim3(1024), 0, c->stream, c->lod_block_sums, nb, c->m_dev, c->lod_qcount);
+    hipLaunchKernelGGL(k_compact_write, dim3(nb), dim3(GSX_CMP_NT), 0, c->stream, c->lod_emit, n, match, c->lod_block_sums,
                        c->sel_idx);
     GSX_HIP(c, hipGetLastError());
     return GSX_OK;
@@ -172,11 +255,39 @@ int gsx_launch_select_octree(gsx_ctx* c, const float vp[16], float thr) {
     GsxMat4 m;
     for (int i = 0; i < 16; ++i) m.m[i] = vp[i];
     if (c->profiling) GSX_HIP(c, hipEventRecord(c->ev[EV_SEL0], c->stream));
-    hipLaunchKernelGGL(k_octree_stop, dim3(gsx_div_up(n, 256)), dim3(256), 0, c->stream, c->lod_a, c->lod_b, c->lod_leaf, n,
-                       m, thr, c->lod_stop);
-    hipLaunchKernelGGL(k_emit_flags, dim3(gsx_div_up(n, 256)), dim3(256), 0, c->stream, c->lod_stop, c->lod_parent, n,
-                       c->lod_emit);
-    const int rc = compact(c, n);
+    uint32_t match = 1u;
+    if (c->lod_levels && !c->opt_lod_walk) {
+        GsxLodLevels lv;
+        for (uint32_t l = 0; l <= GSX_LOD_MAX_LEVELS; ++l) lv.start[l] = l <= c->lod_levels ? c->lod_level_start[l] : n;
+        if (c->lod_stamp >= 255u) {     // stamps are used up (or another path wrote flags into the bytes): start over
+            GSX_HIP(c, hipMemsetAsync(c->lod_emit, 0, (static_cast<uint64_t>(n) + 15) / 16 * 16, c->stream));
+            c->lod_stamp = 0;
+        }
+        match = ++c->lod_stamp;
+        const uint32_t top = c->lod_top_levels;
+        hipLaunchKernelGGL(k_octree_top, dim3(gsx_div_up(lv.start[top] * 8u, GSX_TOP_NT)), dim3(GSX_TOP_NT), 0, c->stream, c->lod_a, c->lod_b,
+                           c->lod_leaf, c->lod_child, c->lod_top_anc, lv.start[top], lv.start[top - 1u], top, m, thr,
+                           static_cast<uint8_t>(match), c->lod_emit, c->lod_queue[top & 1u], c->lod_qcount);
+        for (uint32_t l = top; l < c->lod_levels; ++l) {
+            // (the queue's length is only known on the device: the grid covers the level, workgroups past the queue leave at once)
+            const uint32_t width = lv.start[l + 1] - lv.start[l];
+            if (width <= (256u << 10))
+                hipLaunchKernelGGL(k_octree_level<256>, dim3(gsx_div_up(width, 256)), dim3(256), 0, c->stream, c->lod_a, c->lod_b,
+                                   c->lod_leaf, c->lod_child, l, m, thr, static_cast<uint8_t>(match), c->lod_emit, c->lod_queue[l & 1u],
+                                   c->lod_queue[(l + 1u) & 1u], c->lod_qcount);
+            else
+                hipLaunchKernelGGL(k_octree_level<1024>, dim3(gsx_div_up(width, 1024)), dim3(1024), 0, c->stream, c->lod_a, c->lod_b,
+                                   c->lod_leaf, c->lod_child, l, m, thr, static_cast<uint8_t>(match), c->lod_emit, c->lod_queue[l & 1u],
+                                   c->lod_queue[(l + 1u) & 1u], c->lod_qcount);
+        }
+    } else {
+        c->lod_stamp = 255u;            // the flags below overwrite the stamps
+        hipLaunchKernelGGL(k_octree_stop, dim3(gsx_div_up(n, 256)), dim3(256), 0, c->stream, c->lod_a, c->lod_b, c->lod_leaf, n,
+                           m, thr, c->lod_stop);
+        hipLaunchKernelGGL(k_emit_flags, dim3(gsx_div_up(n, 256)), dim3(256), 0, c->stream, c->lod_stop, c->lod_parent, n,
+                           c->lod_emit);
+    }
+    const int rc = compact(c, n, match);
     if (c->profiling) GSX_HIP(c, hipEventRecord(c->ev[EV_SEL1], c->stream));
     return rc;
 }
@@ -184,6 +295,7 @@ int gsx_launch_select_octree(gsx_ctx* c, const float vp[16], float thr) {
 int gsx_launch_select_hc(gsx_ctx* c, const float cam[3], float thr) {
     const uint32_t n = c->lod_nodes;
     if (c->profiling) GSX_HIP(c, hipEventRecord(c->ev[EV_SEL0], c->stream));
+    c->lod_stamp = 255u;
     hipLaunchKernelGGL(k_hc_stop, dim3(gsx_div_up(n, 256)), dim3(256), 0, c->stream, c->lod_a, c->pos4, c->lod_leaf, n,
                        cam[0], cam[1], cam[2], thr, c->lod_stop);
     hipLaunchKernelGGL(k_emit_flags, dim3(gsx_div_up(n, 256)), dim3(256), 0, c->stream, c->lod_stop, c->lod_parent, n,
@@ -206,6 +318,7 @@ __global__ __launch_bounds__(256) void k_mark_list(const uint32_t* __restrict__ 
 // `list` is a device staging copy of the caller's ids (c->vals[0] is free between sorts).
 int gsx_launch_sort_list(gsx_ctx* c, uint32_t m) {
     const uint32_t n = static_cast<uint32_t>(c->n);
+    c->lod_stamp = 255u;
     GSX_HIP(c, hipMemsetAsync(c->lod_emit, 0, (static_cast<uint64_t>(n) + 15) / 16 * 16, c->stream));
     if (m > 0)
         hipLaunchKernelGGL(k_mark_list, dim3(gsx_div_up(m, 256)), dim3(256), 0, c->stream, c->vals[0], m, n, c->lod_emit,

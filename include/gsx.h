@@ -123,6 +123,9 @@ int gsx_get_sort_samples(gsx_ctx* ctx, double* sum_ms, uint32_t* sorts, int rese
  *                   last frame, the default takes everything behind that window in one iteration)
  *   "no_history"    1 = always pre-queue iterations for the whole selection (default: only as many ranks as
  *                   the last 8 frames needed before every tile was saturated, +25 %; the rest runs on demand)
+ *   "lod_walk"      1 = cut an octree with the general kernels (every node tests itself, then walks its ancestor chain)
+ *                   even when it is laid out in BFS order, for which the default is the top-down level-by-level cut;
+ *                   same result, kept for A/B measurements and as the path for trees in any other order
  * Unknown name -> GSX_E_INVALID. */
 int gsx_set_option(gsx_ctx* ctx, const char* name, uint64_t value);
 

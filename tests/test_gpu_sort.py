@@ -323,3 +323,86 @@ def test_octree_select_large_orbit(gsx, pkg, oracle, synth):
         assert np.all(k[:-1] >= k[1:]) and np.array_equal(np.sort(perm), ref_cut)
     gsx.select_all()
     t.close()
+
+
+def test_octree_non_bfs_layout_uses_the_general_cut(gsx_fresh, oracle):
+    """The level-by-level cut needs BFS order.  The golden tree renumbered in depth-first preorder (parents still precede
+    children, levels no longer contiguous) must give the same SET, through the ancestor-walk kernels."""
+    gsx = gsx_fresh
+    g = golden("lod.npz")
+    fc, nc = g["oc_first_child"], g["oc_n_children"]
+    parent = _octree_parent(fc, nc)
+    n = len(parent)
+    order, stack = [], [0]
+    while stack:                                          # preorder: order[k] = old id of the node numbered k
+        i = stack.pop()
+        order.append(i)
+        stack.extend(range(int(fc[i]) + int(nc[i]) - 1, int(fc[i]) - 1, -1))
+    order = np.array(order)
+    assert len(order) == n
+    new_id = np.empty(n, np.int64)
+    new_id[order] = np.arange(n)
+    p2 = np.full(n, 0xFFFFFFFF, np.uint32)
+    p2[new_id[1:]] = new_id[parent[1:]]
+    assert np.all(p2[1:] < np.arange(1, n)) and np.any(np.diff(p2[1:].astype(np.int64)) < 0)    # topological, not BFS
+    splats = np.zeros((n, 20), np.float32)
+    splats[:, 0] = splats[:, 5] = splats[:, 10] = 0.01
+    splats[:, 15] = 1.0
+    gsx.upload(splats)
+    gsx.set_lod_octree(g["oc_center3"][order], g["oc_half3"][order], p2, (nc == 0).astype(np.uint8)[order])
+    for p in range(3):
+        vp = g["pose_viewproj"][p]
+        for t, thr in enumerate(g["oc_thr"]):
+            m = gsx.select_octree(vp, float(thr))
+            want = np.sort(new_id[g[f"oc_cut_p{p}_t{t}"]]).astype(np.uint32)
+            assert m == len(want) and np.array_equal(gsx.selection(), want)
+
+
+def test_cfg3_octree_orbit_at_6m(gsx_fresh, pkg, oracle, synth):
+    """cfg 3 at full size: 6 M splats -> 8.48 M octree nodes, frames of the 120-frame orbit.  The top-down level-by-level
+    cut against (a) the general ancestor-walk kernels on every tested frame and (b) the host's Octree::get_indices
+    (host/gsx_lod_host.hpp, bit-identical to the reference per tests/test_host.py) on three of them; then the
+    LOD -> sort -> frame chain by properties."""
+    import importlib
+    lod = importlib.import_module("gaussian_splatting_amd.lod")
+    gsx = gsx_fresh
+    t = lod.build_octree(synth.clustered_cloud(6_000_000, seed=6))
+    assert t.n > 8_000_000
+    t.upload(gsx)
+    w, h = 1920, 1080
+    sizes = []
+    for f in range(0, 120, 8):
+        world, _ = oracle.orbit_world(5.0, (0.0, 1.0, 0.0), 2.0 * np.pi / 120.0, f)
+        view, proj, vp, cam = oracle.camera(world, 45.0, w / h)
+        gsx.set_option("lod_walk", 1)
+        m_walk = gsx.select_octree(vp, 0.002)
+        walk = gsx.selection()
+        gsx.set_option("lod_walk", 0)
+        m = gsx.select_octree(vp, 0.002)
+        cut = gsx.selection()
+        assert m == m_walk and np.array_equal(cut, walk)
+        assert np.all(cut[1:] > cut[:-1]) and 100_000 < m < t.n
+        sizes.append(m)
+        if f % 40 == 0:
+            ref = np.sort(t.cut_camera(world, 0.002, 45.0, w / h))
+            assert np.array_equal(cut, ref)
+            perm = gsx.sort(cam)
+            assert np.array_equal(np.sort(perm), cut)                  # the sort permutes exactly the cut
+            k = oracle.distance_keys(t.splats[perm], cam)
+            assert np.all(k[:-1] >= k[1:])
+            u = pkg.make_uniforms(proj, view)
+            img = gsx.render(u, w, h)
+            assert np.all(img[..., 3] == 255) and img[..., :3].std() > 10
+            assert np.array_equal(gsx.render(u, w, h), img)
+    assert len(set(sizes)) > 4                                          # the cut follows the camera
+    # a finer and a coarser threshold, and the extremes: everything stops at the root / nothing stops before the leaves
+    world, _ = oracle.orbit_world(5.0, (0.0, 1.0, 0.0), 0.3, 1)
+    view, proj, vp, cam = oracle.camera(world, 45.0, w / h)
+    for thr in (0.0002, 0.05):
+        m = gsx.select_octree(vp, thr)
+        assert np.array_equal(gsx.selection(), np.sort(t.cut_camera(world, thr, 45.0, w / h)))
+    assert gsx.select_octree(vp, 1e9) == 1 and gsx.selection()[0] == 0
+    m = gsx.select_octree(vp, 0.0)
+    assert m == int(t.is_leaf.sum()) and np.array_equal(gsx.selection(), np.nonzero(t.is_leaf)[0].astype(np.uint32))
+    gsx.select_all()
+    t.close()

@@ -65,6 +65,9 @@ def cfg3():
         poses.append((pkg.make_uniforms(proj, view), pos, vp))
     with pkg.Gsx(0) as g:
         tree.upload(g)
+        for o in os.environ.get("GSX_OPTS", "").split():      # A/B runs: GSX_OPTS="lod_walk=1"
+            k, val = o.split("=")
+            g.set_option(k, int(val))
         ms = []
         for f in range(0, frames, 30):          # cut sizes along the orbit (read back, outside the timing)
             ms.append(int(g.select_octree(poses[f][2], 0.002)))
@@ -82,7 +85,8 @@ def cfg3():
         t = g.timings()
     emit({"config": "cfg3", "splats": n, "octree_nodes": int(tree.n), "host_octree_build_s": build_s, "frames": frames,
           "what": "octree cut (threshold 0.002) -> sort -> 1080p frame per orbit step", "cut_sizes_at_frames_0_30_60_90": ms,
-          "ms_per_frame": dt * 1e3, "fps": 1.0 / dt, "last_frame_tile_pairs": t["tile_pairs"], "last_frame_iters": t["render_iters"]})
+          "ms_per_frame": dt * 1e3, "fps": 1.0 / dt, "last_frame_tile_pairs": t["tile_pairs"], "last_frame_iters": t["render_iters"],
+          "opts": os.environ.get("GSX_OPTS", "")})
     tree.close()
 
 
