@@ -87,6 +87,11 @@ int gsx_create(int device, gsx_ctx** out) {
     auto fail = [&](int rc) { gsx_destroy(c); return rc; };
     if (hipSetDevice(device) != hipSuccess) return fail(GSX_E_HIP);
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return fail(GSX_E_HIP);
+    if (hipStreamCreateWithFlags(&c->sort_stream, hipStreamNonBlocking) != hipSuccess) return fail(GSX_E_HIP);
+    if (hipEventCreateWithFlags(&c->ev_sorted, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_pre, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_frame_done[0], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_frame_done[1], hipEventDisableTiming) != hipSuccess)
+        return fail(GSX_E_HIP);
     if (gsx_scratch_init(c, device) != GSX_OK) return fail(GSX_E_HIP);
     {
         int cus = 0;
@@ -128,6 +133,7 @@ int gsx_destroy(gsx_ctx* c) {
     if (!c) return GSX_E_INVALID;
     (void)hipSetDevice(c->device);
     c->frame_pending = false;
+    if (c->sort_stream) (void)hipStreamSynchronize(c->sort_stream);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     dev_free(&c->pos4); dev_free(&c->geo);
     dev_free(&c->sel_idx); dev_free(&c->m_dev);
@@ -147,6 +153,9 @@ int gsx_destroy(gsx_ctx* c) {
     if (c->flags_host) (void)hipHostFree(c->flags_host);
     for (int i = 0; i < EV_COUNT; ++i)
         if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+    for (hipEvent_t e : {c->ev_sorted, c->ev_pre, c->ev_frame_done[0], c->ev_frame_done[1]})
+        if (e) (void)hipEventDestroy(e);
+    if (c->sort_stream) (void)hipStreamDestroy(c->sort_stream);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return GSX_OK;
@@ -175,6 +184,8 @@ int gsx_set_option(gsx_ctx* c, const char* name, uint64_t value) {
         c->opt_no_history = value ? 1 : 0;
     } else if (!std::strcmp(name, "lod_walk")) {
         c->opt_lod_walk = value ? 1 : 0;
+    } else if (!std::strcmp(name, "async_sort")) {
+        c->opt_async_sort = value ? 1 : 0;
     } else {
         c->err = std::string("unknown option: ") + name;
         return GSX_E_INVALID;
@@ -187,6 +198,7 @@ int gsx_set_profiling(gsx_ctx* c, int enabled) {
     if (enabled < 0 || enabled > 2) return GSX_E_INVALID;
     c->prof_level = enabled;
     c->profiling = enabled == 1;
+    c->prof_frame = 0;                 // (the next sort is a sampled one at level 2)
     return GSX_OK;
 }
 
@@ -277,6 +289,8 @@ int gsx_get_timings(gsx_ctx* c, gsx_timings* out) {
 static int upload_common(gsx_ctx* c, const void* aos_dev, uint64_t n) {
     int rc;
     if ((rc = gsx_frame_finish(c))) return rc;
+    c->main_dirty = true;
+    c->frame_done_rec[0] = c->frame_done_rec[1] = false;
     if ((rc = alloc_scene(c, n))) return rc;
     c->n = n;
     GSX_HIP(c, hipMemsetAsync(c->flags, 0, sizeof(GsxDevFlags), c->stream));
@@ -323,6 +337,7 @@ int gsx_select_all(gsx_ctx* c) {
     int rc = set_device(c);
     if (rc) return rc;
     if ((rc = gsx_frame_finish(c))) return rc;
+    c->main_dirty = true;
     c->sel_iota = true;
     c->m_cap = static_cast<uint32_t>(c->n);
     c->sorted_valid = false;
@@ -338,6 +353,7 @@ int gsx_select_list(gsx_ctx* c, const uint32_t* idx_host, uint32_t m) {
     int rc = set_device(c);
     if (rc) return rc;
     if ((rc = gsx_frame_finish(c))) return rc;
+    c->main_dirty = true;
     if (m) GSX_HIP(c, hipMemcpyAsync(c->vals[0], idx_host, static_cast<uint64_t>(m) * 4, hipMemcpyHostToDevice, c->stream));
     if ((rc = gsx_launch_sort_list(c, m))) return rc;
     c->sel_iota = false;
@@ -468,6 +484,7 @@ int gsx_select_octree(gsx_ctx* c, const float viewproj[16], float min_screen_are
     int rc = set_device(c);
     if (rc) return rc;
     if ((rc = gsx_frame_finish(c))) return rc;
+    c->main_dirty = true;
     if ((rc = gsx_launch_select_octree(c, viewproj, min_screen_area))) return rc;
     return finish_select(c, m_out);
 }
@@ -478,6 +495,7 @@ int gsx_select_hc(gsx_ctx* c, const float cam_pos[3], float threshold, uint32_t*
     int rc = set_device(c);
     if (rc) return rc;
     if ((rc = gsx_frame_finish(c))) return rc;
+    c->main_dirty = true;
     if ((rc = gsx_launch_select_hc(c, cam_pos, threshold))) return rc;
     return finish_select(c, m_out);
 }
@@ -525,9 +543,11 @@ int gsx_sort_noalloc(gsx_ctx* c, const float cam_pos[3], uint32_t* idx_out_dev, 
     if (capacity < c->m_cap) { c->err = "gsx_sort_noalloc: output buffer smaller than the selection"; return GSX_E_INVALID; }
     int rc = set_device(c);
     if (rc) return rc;
+    gsx_join_sort(c);
     const float keep[3] = {c->cam[0], c->cam[1], c->cam[2]};   // (the frame loop's schedule looks at the camera of the context's own sorts)
     c->cam[0] = cam_pos[0]; c->cam[1] = cam_pos[1]; c->cam[2] = cam_pos[2];
     rc = gsx_launch_sort_noalloc(c, idx_out_dev);     // queued on the context's stream; no allocation, no readback, no wait
+    c->main_dirty = true;                             // (shares the gated-pass counter with the context's own sort: keep them in order)
     c->cam[0] = keep[0]; c->cam[1] = keep[1]; c->cam[2] = keep[2];
     return rc;
 }

@@ -11,6 +11,7 @@
 #define GSX_WAVE 64
 #define GSX_SAMPLE_RING 32
 #define GSX_SAMPLE_WHOLE 4
+#define GSX_SAMPLE_EVERY 4u       // profiling level 2 samples every 4th sort
 #define GSX_LOD_MAX_LEVELS 48
 #define GSX_LOD_TOP_NODES 4096u      // nodes of the leading octree levels one workgroup walks in LDS     // sample slot of "keys + sort as a whole" (slots 0..3: the scatter launch of a radix pass)
 #define GSX_STAT_BYTES (64 * 16 * 8)   // rasterizer counters (profiling level 1): 64 shards x one 128-byte line of u64 words
@@ -214,6 +215,19 @@ struct gsx_ctx {
     bool frame_pending = false;
     // tuning (gsx_set_option); 0 = automatic
     uint64_t opt_pair_budget = 0, opt_chunk_first = 0, opt_chunk_growth = 0, opt_no_history = 0, opt_lod_walk = 0;
+    // The depth sort of frame k+1 runs on a stream of its own, beside the binning / rasterizing of frame k (it writes the
+    // OTHER permutation buffer and its own key / value arrays).  Ordering is by events:
+    //   sort stream waits for   ev_pre         (main stream, recorded when a selection / upload was queued since the last sort)
+    //                           ev_frame_done[b] (main stream: the last frame that read permutation buffer b is complete)
+    //   main stream waits for   ev_sorted      (sort stream: end of the latest sort) before anything that reads the permutation
+    //                                           or rewrites what the sort reads (gsx_frame_finish does the join)
+    uint64_t opt_async_sort = 1;
+    hipStream_t sort_stream = nullptr;
+    hipEvent_t ev_sorted = nullptr, ev_pre = nullptr, ev_frame_done[2] = {nullptr, nullptr};
+    bool frame_done_rec[2] = {false, false};
+    bool sort_join_pending = false;      // a sort was queued on sort_stream and the main stream has not waited for it yet
+    bool main_dirty = true;              // the main stream holds work the next sort must see (selection, upload): record ev_pre
+    bool pre_wait = false;               // ev_pre is recorded and the sort stream has not waited for it yet
 
     // timing
     hipEvent_t ev[40] = {};
@@ -272,4 +286,5 @@ int gsx_launch_select_hc(gsx_ctx* c, const float cam[3], float thr);
 int gsx_launch_sort_list(gsx_ctx* c, uint32_t m); // ascending re-order of an explicit index list
 int gsx_launch_render(gsx_ctx* c, const gsx_uniforms* u, uint32_t w, uint32_t h, uint32_t y0, uint32_t y1);
 void gsx_sample_drain(gsx_ctx* c, uint32_t slot);   // folds a finished level-2 sample into samp_sum_ms / samp_n
+void gsx_join_sort(gsx_ctx* c);                  // main stream waits for the sort stream's latest sort (no host wait)
 int gsx_frame_finish(gsx_ctx* c);                // waits for the queued frame; runs extra iterations if ranks are left

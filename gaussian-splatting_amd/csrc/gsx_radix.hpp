@@ -376,7 +376,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 #ifdef GSX_ABL_NOWRITE
                 if (k == static_cast<KeyT>(0x12345677u) && dst == 0x7FFFFFFFu)
 #endif
-                {
+                if (dst < count) {   // (always true for a consistent count matrix; a corrupted one must not become a stray write)
                 keys_out[dst] = k;
                 vals_out[dst] = s_vals[p];
                 }

@@ -807,6 +807,13 @@ static int launch_iteration(gsx_ctx* c, uint32_t iter, uint32_t window, bool fir
     return GSX_OK;
 }
 
+// Everything queued so far for the frame in flight reads permutation buffer b: the sort that overwrites b next waits for this.
+static void gsx_mark_frame_done(gsx_ctx* c) {
+    const uint32_t b = c->frame.sorted == c->perm[1] ? 1u : 0u;
+    if (!c->ev_frame_done[b]) return;
+    if (hipEventRecord(c->ev_frame_done[b], c->stream) == hipSuccess) c->frame_done_rec[b] = true;
+}
+
 int gsx_launch_render(gsx_ctx* c, const gsx_uniforms* u, uint32_t w, uint32_t h, uint32_t y0, uint32_t y1) {
     static_assert(sizeof(GsxViewParams) <= sizeof(c->frame.vp_blob), "vp_blob too small");
     const float* P = u->projectionMatrix;
@@ -948,6 +955,7 @@ int gsx_launch_render(gsx_ctx* c, const gsx_uniforms* u, uint32_t w, uint32_t h,
     f.n_iters = n_iters;
     GSX_HIP(c, hipMemcpyAsync(c->ctl_host, c->ctl, GSX_AUX_OFFSET + 128, hipMemcpyDeviceToHost, c->stream));   // control block + aux
     GSX_HIP(c, hipEventRecord(c->frame_ev, c->stream));
+    gsx_mark_frame_done(c);
     c->frame_pending = true;
     if (c->profiling) GSX_HIP(c, hipEventRecord(c->ev[EV_RAST1], c->stream));
     GSX_HIP(c, hipGetLastError());
@@ -957,6 +965,7 @@ int gsx_launch_render(gsx_ctx* c, const gsx_uniforms* u, uint32_t w, uint32_t h,
 // Waits for the frame queued by gsx_launch_render and, if the device could not fit every rank into
 // the scheduled iterations (pair budget hit), keeps running iterations until the cursor reaches m.
 int gsx_frame_finish(gsx_ctx* c) {
+    gsx_join_sort(c);      // whatever the caller queues next may read the permutation or rewrite the sort's inputs
     if (!c->frame_pending) return GSX_OK;
     GSX_HIP(c, hipEventSynchronize(c->frame_ev));
     GsxFrameState& f = c->frame;
@@ -988,6 +997,7 @@ int gsx_frame_finish(gsx_ctx* c) {
         GSX_HIP(c, hipMemcpyAsync(&c->ctl->stall, &zero, 4, hipMemcpyHostToDevice, c->stream));
         if ((rc = launch_iteration(c, 0, h.m - cur, false)) != GSX_OK) { c->frame_pending = false; return rc; }
         GSX_HIP(c, hipMemcpyAsync(c->ctl_host, c->ctl, GSX_AUX_OFFSET + 128, hipMemcpyDeviceToHost, c->stream));
+        gsx_mark_frame_done(c);
         GSX_HIP(c, hipStreamSynchronize(c->stream));
         last = 1;
     }

@@ -227,7 +227,7 @@ struct GsxSortBuffers {
     bool with_events;      // profiling events / sampled scatter launches (the context's own sort only)
 };
 
-static int launch_sort_in(gsx_ctx* c, const GsxSortBuffers& sb) {
+static int launch_sort_in(gsx_ctx* c, const GsxSortBuffers& sb, hipStream_t st) {
     const uint32_t cap = c->m_cap;
     const uint32_t g = gsx_radix_blocks(cap, GSX_SORT_TILE, c->sort_slots);
     const uint32_t cols = gsx_radix_columns(c->sort_slots);
@@ -245,14 +245,15 @@ static int launch_sort_in(gsx_ctx* c, const GsxSortBuffers& sb) {
     const uint32_t top_bits = total_bits > LOW_BITS ? total_bits - LOW_BITS : 0u;
     const GsxRadixPlan plan = gsx_radix_plan(top_bits ? LOW_BITS : total_bits);
     const uint32_t wide_mask = top_bits ? ~((1u << LOW_BITS) - 1u) : 0u;
-    if (top_bits) GSX_HIP(c, hipMemsetAsync(&c->flags->wide_m, 0, sizeof(uint32_t), c->stream));
-    // Profiling level 2 brackets ONE thing per sort with a pair of events from the ring, rotating sort by sort: the scatter
-    // launch of pass 0, 1, ..., and (slot GSX_SAMPLE_WHOLE) the whole of keys + sort, from before the key kernel to behind
-    // the last pass.
+    if (top_bits) GSX_HIP(c, hipMemsetAsync(&c->flags->wide_m, 0, sizeof(uint32_t), st));
+    // Profiling level 2 brackets ONE thing in every GSX_SAMPLE_EVERY-th sort with a pair of events from the ring, rotating:
+    // the scatter launch of pass 0, 1, ..., and (slot GSX_SAMPLE_WHOLE) the whole of keys + sort, from before the key kernel
+    // to behind the last pass.  A sampled sort runs on the main stream (gsx_launch_sort), i.e. NOT beside the previous
+    // frame's rasterizer, so that the bracket measures the kernel and not its share of a GPU it has to split.
     int sampled_pass = -1;
     if (sb.with_events) {
-        if (c->prof_level == 2 && plan.n_passes > 0) {
-            const uint32_t turn = c->prof_frame % (static_cast<uint32_t>(plan.n_passes) + 1u);
+        if (c->prof_level == 2 && plan.n_passes > 0 && c->prof_frame % GSX_SAMPLE_EVERY == 0u) {
+            const uint32_t turn = (c->prof_frame / GSX_SAMPLE_EVERY) % (static_cast<uint32_t>(plan.n_passes) + 1u);
             sampled_pass = turn == static_cast<uint32_t>(plan.n_passes) ? GSX_SAMPLE_WHOLE : static_cast<int>(turn);
         }
         c->sampled_pass = sampled_pass;
@@ -266,38 +267,38 @@ static int launch_sort_in(gsx_ctx* c, const GsxSortBuffers& sb) {
         samp0 = c->samp_ev[slot][0];
         samp1 = c->samp_ev[slot][1];
     }
-    if (sampled_pass == GSX_SAMPLE_WHOLE) GSX_HIP(c, hipEventRecord(samp0, c->stream));
-    if (profiling) GSX_HIP(c, hipEventRecord(c->ev[EV_KEY0], c->stream));
+    if (sampled_pass == GSX_SAMPLE_WHOLE) GSX_HIP(c, hipEventRecord(samp0, st));
+    if (profiling) GSX_HIP(c, hipEventRecord(c->ev[EV_KEY0], st));
     if (c->sel_iota)
-        hipLaunchKernelGGL(k_keygen_hist0<true>, dim3(g), dim3(GSX_SORT_NT), 0, c->stream, c->pos4, nullptr, c->m_dev, c->cam[0],
+        hipLaunchKernelGGL(k_keygen_hist0<true>, dim3(g), dim3(GSX_SORT_NT), 0, st, c->pos4, nullptr, c->m_dev, c->cam[0],
                            c->cam[1], c->cam[2], key_lo, key_span, plan.shift[0], plan.bits[0], wide_mask, sb.keys[0], sb.ws, cols,
                            c->flags);
     else
-        hipLaunchKernelGGL(k_keygen_hist0<false>, dim3(g), dim3(GSX_SORT_NT), 0, c->stream, c->pos4, c->sel_idx, c->m_dev, c->cam[0],
+        hipLaunchKernelGGL(k_keygen_hist0<false>, dim3(g), dim3(GSX_SORT_NT), 0, st, c->pos4, c->sel_idx, c->m_dev, c->cam[0],
                            c->cam[1], c->cam[2], key_lo, key_span, plan.shift[0], plan.bits[0], wide_mask, sb.keys[0], sb.ws, cols,
                            c->flags);
-    if (profiling) GSX_HIP(c, hipEventRecord(c->ev[EV_KEY1], c->stream));
+    if (profiling) GSX_HIP(c, hipEventRecord(c->ev[EV_KEY1], st));
     uint32_t cur = 0;
     uint32_t* result = sb.result;
     for (int p = 0; p < plan.n_passes; ++p) {
         const bool first = p == 0, last = p + 1 == plan.n_passes;
         hipEvent_t e0 = profiling ? c->ev[EV_X0 + 2 * p] : (sampled_pass == p ? samp0 : nullptr);
         hipEvent_t e1 = profiling ? c->ev[EV_X0 + 2 * p + 1] : (sampled_pass == p ? samp1 : nullptr);
-        launch_pass<uint32_t, GSX_SORT_NT, GSX_SORT_IPT>(c, c->stream, g, sb.keys[cur], first ? c->sel_idx : sb.vals[cur], sb.keys[cur ^ 1],
+        launch_pass<uint32_t, GSX_SORT_NT, GSX_SORT_IPT>(c, st, g, sb.keys[cur], first ? c->sel_idx : sb.vals[cur], sb.keys[cur ^ 1],
                                                           last ? result : sb.vals[cur ^ 1], c->m_dev, plan.shift[p], plan.bits[p], sb.ws,
                                                           cols, /*need_hist=*/!first, /*iota=*/first && c->sel_iota, e0, e1);
         cur ^= 1;
     }
     if (top_bits) {   // gated top digit: result -> scratch values, then back (all four kernels see count 0 in the common case)
         static_assert(EV_X0 + 2 * 3 + 1 < EV_X_END, "event slots of the gated pass");
-        launch_pass<uint32_t, GSX_SORT_NT, GSX_SORT_IPT>(c, c->stream, g, sb.keys[cur], result, sb.keys[cur ^ 1], sb.vals[cur ^ 1],
+        launch_pass<uint32_t, GSX_SORT_NT, GSX_SORT_IPT>(c, st, g, sb.keys[cur], result, sb.keys[cur ^ 1], sb.vals[cur ^ 1],
                                                           &c->flags->wide_m, LOW_BITS, top_bits, sb.ws, cols, /*need_hist=*/true,
                                                           /*iota=*/false, profiling ? c->ev[EV_X0 + 6] : nullptr,
                                                           profiling ? c->ev[EV_X0 + 7] : nullptr);
-        hipLaunchKernelGGL(k_copy_gated, dim3(g), dim3(512), 0, c->stream, &c->flags->wide_m, sb.vals[cur ^ 1], result);
+        hipLaunchKernelGGL(k_copy_gated, dim3(g), dim3(512), 0, st, &c->flags->wide_m, sb.vals[cur ^ 1], result);
     }
-    if (sampled_pass == GSX_SAMPLE_WHOLE) GSX_HIP(c, hipEventRecord(samp1, c->stream));
-    if (profiling) GSX_HIP(c, hipEventRecord(c->ev[EV_SORT1], c->stream));
+    if (sampled_pass == GSX_SAMPLE_WHOLE) GSX_HIP(c, hipEventRecord(samp1, st));
+    if (profiling) GSX_HIP(c, hipEventRecord(c->ev[EV_SORT1], st));
     GSX_HIP(c, hipGetLastError());
     if (sb.with_events) {   // (the context's own sort: what gsx_get_timings reports)
         c->sort_passes = static_cast<uint32_t>(plan.n_passes) + (top_bits ? 1u : 0u);   // (the gated pass counts as launched)
@@ -306,16 +307,50 @@ static int launch_sort_in(gsx_ctx* c, const GsxSortBuffers& sb) {
     return GSX_OK;
 }
 
+void gsx_join_sort(gsx_ctx* c) {
+    if (!c->sort_join_pending) return;
+    (void)hipStreamWaitEvent(c->stream, c->ev_sorted, 0);
+    c->sort_join_pending = false;
+}
+
 int gsx_launch_sort(gsx_ctx* c) {
     GsxSortBuffers sb;
     sb.keys[0] = c->keys[0]; sb.keys[1] = c->keys[1];
     sb.vals[0] = c->vals[0]; sb.vals[1] = c->vals[1];
     sb.ws = c->sort_ws;
     sb.ws_words = c->sort_ws_words;
-    sb.result = c->perm[c->perm_cur ^ 1u];
+    const uint32_t target = c->perm_cur ^ 1u;
+    sb.result = c->perm[target];
     sb.with_events = true;
-    const int rc = launch_sort_in(c, sb);
+    // (with every stage bracketed by events - profiling level 1 - the stages run one after another on the main stream, and so
+    // does a sort that carries a level-2 sample)
+    const bool sampled = c->prof_level == 2 && c->prof_frame % GSX_SAMPLE_EVERY == 0u;
+    const bool async = c->opt_async_sort && c->sort_stream && !c->profiling && !sampled;
+    hipStream_t st = c->stream;
+    if (async) {
+        st = c->sort_stream;
+        if (c->main_dirty) {             // a selection or an upload queued on the main stream since the last sort
+            GSX_HIP(c, hipEventRecord(c->ev_pre, c->stream));
+            c->pre_wait = true;
+            c->main_dirty = false;
+        }
+        // ev_pre: the point of the main stream this sort must be behind (selection / upload, or a sort that ran on the main
+        // stream itself - a sampled one - and used the same key / value / count arrays)
+        if (c->pre_wait) { GSX_HIP(c, hipStreamWaitEvent(st, c->ev_pre, 0)); c->pre_wait = false; }
+        // the last frame that drew from the buffer this sort overwrites (the frame before the one in flight)
+        if (c->frame_done_rec[target]) GSX_HIP(c, hipStreamWaitEvent(st, c->ev_frame_done[target], 0));
+    } else {
+        gsx_join_sort(c);                // behind the sort stream's latest sort: same arrays
+    }
+    const int rc = launch_sort_in(c, sb, st);
     if (rc != GSX_OK) return rc;
+    if (async) {
+        GSX_HIP(c, hipEventRecord(c->ev_sorted, st));
+        c->sort_join_pending = true;
+    } else if (c->sort_stream) {
+        GSX_HIP(c, hipEventRecord(c->ev_pre, c->stream));   // the next sort on the sort stream starts behind this one
+        c->pre_wait = true;
+    }
     c->perm_cur ^= 1u;
     c->sorted_valid = true;
     return GSX_OK;
@@ -368,7 +403,7 @@ int gsx_launch_sort_noalloc(gsx_ctx* c, uint32_t* idx_out_dev) {
     // Nothing in the scratch has to start at zero: every count-matrix column a pass reads was written by the same
     // pass's count kernel (their column count derives from the same device-side key count), and keys / values are
     // written before they are read; what an earlier, larger call left behind is never looked at.
-    return launch_sort_in(c, sb);
+    return launch_sort_in(c, sb, c->stream);
 }
 
 
