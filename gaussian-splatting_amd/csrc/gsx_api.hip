@@ -90,8 +90,10 @@ int gsx_create(int device, gsx_ctx** out) {
     if (hipStreamCreateWithFlags(&c->sort_stream, hipStreamNonBlocking) != hipSuccess) return fail(GSX_E_HIP);
     if (hipEventCreateWithFlags(&c->ev_sorted, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_pre, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_frame_done[0], hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_frame_done[1], hipEventDisableTiming) != hipSuccess)
+        hipEventCreateWithFlags(&c->ev_frame_done[1], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_frame_init, hipEventDisableTiming) != hipSuccess)
         return fail(GSX_E_HIP);
+    c->sel_stream = c->stream;
     if (gsx_scratch_init(c, device) != GSX_OK) return fail(GSX_E_HIP);
     {
         int cus = 0;
@@ -153,7 +155,7 @@ int gsx_destroy(gsx_ctx* c) {
     if (c->flags_host) (void)hipHostFree(c->flags_host);
     for (int i = 0; i < EV_COUNT; ++i)
         if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
-    for (hipEvent_t e : {c->ev_sorted, c->ev_pre, c->ev_frame_done[0], c->ev_frame_done[1]})
+    for (hipEvent_t e : {c->ev_sorted, c->ev_pre, c->ev_frame_done[0], c->ev_frame_done[1], c->ev_frame_init})
         if (e) (void)hipEventDestroy(e);
     if (c->sort_stream) (void)hipStreamDestroy(c->sort_stream);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -291,6 +293,7 @@ static int upload_common(gsx_ctx* c, const void* aos_dev, uint64_t n) {
     if ((rc = gsx_frame_finish(c))) return rc;
     c->main_dirty = true;
     c->frame_done_rec[0] = c->frame_done_rec[1] = false;
+    c->frame_init_rec = false;
     if ((rc = alloc_scene(c, n))) return rc;
     c->n = n;
     GSX_HIP(c, hipMemsetAsync(c->flags, 0, sizeof(GsxDevFlags), c->stream));
@@ -465,14 +468,43 @@ int gsx_set_lod_hc(gsx_ctx* c, const gsx_hc_flat* f) {
     return GSX_OK;
 }
 
+// A camera-dependent cut feeds the next sort and nothing else, so it is queued where that sort runs: on the sort stream,
+// beside the frame in flight, which has no use for the selection once its first kernel has read the size (ev_frame_init).
+// Returns the stream in c->sel_stream.  Without the second stream (or with every stage bracketed) the cut waits for the
+// frame and goes to the main stream.
+static int begin_select(gsx_ctx* c) {
+    const bool async = c->opt_async_sort && c->sort_stream && !c->profiling;
+    if (!async) {
+        c->sel_stream = c->stream;
+        const int rc = gsx_frame_finish(c);
+        c->main_dirty = true;
+        return rc;
+    }
+    hipStream_t st = c->sel_stream = c->sort_stream;
+    if (c->main_dirty) {                 // an upload or an explicit selection queued on the main stream
+        GSX_HIP(c, hipEventRecord(c->ev_pre, c->stream));
+        c->pre_wait = true;
+        c->main_dirty = false;
+    }
+    if (c->pre_wait) { GSX_HIP(c, hipStreamWaitEvent(st, c->ev_pre, 0)); c->pre_wait = false; }
+    if (c->frame_init_rec) GSX_HIP(c, hipStreamWaitEvent(st, c->ev_frame_init, 0));
+    return GSX_OK;
+}
+
 static int finish_select(gsx_ctx* c, uint32_t* m_out) {
     c->sel_iota = false;
     c->m_cap = c->lod_nodes;
     c->sorted_valid = false;
     c->ev_recorded[EV_SEL1] = c->profiling;
+    hipStream_t st = c->sel_stream;
+    if (st != c->stream) {               // the main stream joins before it touches the selection (gsx_join_sort)
+        GSX_HIP(c, hipEventRecord(c->ev_sorted, st));
+        c->sort_join_pending = true;
+    }
+    c->sel_stream = c->stream;
     if (m_out) {
-        GSX_HIP(c, hipMemcpyAsync(c->host_word, c->m_dev, 4, hipMemcpyDeviceToHost, c->stream));
-        GSX_HIP(c, hipStreamSynchronize(c->stream));
+        GSX_HIP(c, hipMemcpyAsync(c->host_word, c->m_dev, 4, hipMemcpyDeviceToHost, st));
+        GSX_HIP(c, hipStreamSynchronize(st));
         *m_out = *c->host_word;
     }
     return GSX_OK;
@@ -483,9 +515,8 @@ int gsx_select_octree(gsx_ctx* c, const float viewproj[16], float min_screen_are
     if (c->lod_kind != 1) { c->err = "gsx_select_octree without gsx_set_lod_octree"; return GSX_E_STATE; }
     int rc = set_device(c);
     if (rc) return rc;
-    if ((rc = gsx_frame_finish(c))) return rc;
-    c->main_dirty = true;
-    if ((rc = gsx_launch_select_octree(c, viewproj, min_screen_area))) return rc;
+    if ((rc = begin_select(c))) return rc;
+    if ((rc = gsx_launch_select_octree(c, viewproj, min_screen_area))) { c->sel_stream = c->stream; return rc; }
     return finish_select(c, m_out);
 }
 
@@ -494,9 +525,8 @@ int gsx_select_hc(gsx_ctx* c, const float cam_pos[3], float threshold, uint32_t*
     if (c->lod_kind != 2) { c->err = "gsx_select_hc without gsx_set_lod_hc"; return GSX_E_STATE; }
     int rc = set_device(c);
     if (rc) return rc;
-    if ((rc = gsx_frame_finish(c))) return rc;
-    c->main_dirty = true;
-    if ((rc = gsx_launch_select_hc(c, cam_pos, threshold))) return rc;
+    if ((rc = begin_select(c))) return rc;
+    if ((rc = gsx_launch_select_hc(c, cam_pos, threshold))) { c->sel_stream = c->stream; return rc; }
     return finish_select(c, m_out);
 }
 
@@ -504,6 +534,7 @@ int gsx_get_selection(gsx_ctx* c, uint32_t* idx_out, uint32_t capacity, uint32_t
     if (!c || !m_out) return GSX_E_INVALID;
     int rc = set_device(c);
     if (rc) return rc;
+    gsx_join_sort(c);
     GSX_HIP(c, hipMemcpyAsync(c->host_word, c->m_dev, 4, hipMemcpyDeviceToHost, c->stream));
     GSX_HIP(c, hipStreamSynchronize(c->stream));
     const uint32_t m = *c->host_word;

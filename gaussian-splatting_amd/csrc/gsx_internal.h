@@ -223,6 +223,9 @@ struct gsx_ctx {
     //                                           or rewrites what the sort reads (gsx_frame_finish does the join)
     uint64_t opt_async_sort = 1;
     hipStream_t sort_stream = nullptr;
+    hipStream_t sel_stream = nullptr;     // where the selection kernels of the current call are queued (main or sort stream)
+    hipEvent_t ev_frame_init = nullptr;   // main stream: the frame in flight has read the selection's size (k_frame_init)
+    bool frame_init_rec = false;
     hipEvent_t ev_sorted = nullptr, ev_pre = nullptr, ev_frame_done[2] = {nullptr, nullptr};
     bool frame_done_rec[2] = {false, false};
     bool sort_join_pending = false;      // a sort was queued on sort_stream and the main stream has not waited for it yet

@@ -242,9 +242,9 @@ __global__ __launch_bounds__(GSX_CMP_NT) void k_compact_write(const uint8_t* __r
 // ids whose flag byte equals `match`, ascending
 static int compact(gsx_ctx* c, uint32_t n, uint32_t match = 1u) {
     const uint32_t nb = gsx_div_up(n, GSX_CMP_TILE);
-    hipLaunchKernelGGL(k_compact_count, dim3(nb), dim3(GSX_CMP_NT), 0, c->stream, c->lod_emit, n, match, c->lod_block_sums);
-    hipLaunchKernelGGL(k_scan_block_sums, dim3(1), dim3(1024), 0, c->stream, c->lod_block_sums, nb, c->m_dev, c->lod_qcount);
-    hipLaunchKernelGGL(k_compact_write, dim3(nb), dim3(GSX_CMP_NT), 0, c->stream, c->lod_emit, n, match, c->lod_block_sums,
+    hipLaunchKernelGGL(k_compact_count, dim3(nb), dim3(GSX_CMP_NT), 0, c->sel_stream, c->lod_emit, n, match, c->lod_block_sums);
+    hipLaunchKernelGGL(k_scan_block_sums, dim3(1), dim3(1024), 0, c->sel_stream, c->lod_block_sums, nb, c->m_dev, c->lod_qcount);
+    hipLaunchKernelGGL(k_compact_write, dim3(nb), dim3(GSX_CMP_NT), 0, c->sel_stream, c->lod_emit, n, match, c->lod_block_sums,
                        c->sel_idx);
     GSX_HIP(c, hipGetLastError());
     return GSX_OK;
@@ -254,54 +254,54 @@ int gsx_launch_select_octree(gsx_ctx* c, const float vp[16], float thr) {
     const uint32_t n = c->lod_nodes;
     GsxMat4 m;
     for (int i = 0; i < 16; ++i) m.m[i] = vp[i];
-    if (c->profiling) GSX_HIP(c, hipEventRecord(c->ev[EV_SEL0], c->stream));
+    if (c->profiling) GSX_HIP(c, hipEventRecord(c->ev[EV_SEL0], c->sel_stream));
     uint32_t match = 1u;
     if (c->lod_levels && !c->opt_lod_walk) {
         GsxLodLevels lv;
         for (uint32_t l = 0; l <= GSX_LOD_MAX_LEVELS; ++l) lv.start[l] = l <= c->lod_levels ? c->lod_level_start[l] : n;
         if (c->lod_stamp >= 255u) {     // stamps are used up (or another path wrote flags into the bytes): start over
-            GSX_HIP(c, hipMemsetAsync(c->lod_emit, 0, (static_cast<uint64_t>(n) + 15) / 16 * 16, c->stream));
+            GSX_HIP(c, hipMemsetAsync(c->lod_emit, 0, (static_cast<uint64_t>(n) + 15) / 16 * 16, c->sel_stream));
             c->lod_stamp = 0;
         }
         match = ++c->lod_stamp;
         const uint32_t top = c->lod_top_levels;
-        hipLaunchKernelGGL(k_octree_top, dim3(gsx_div_up(lv.start[top] * 8u, GSX_TOP_NT)), dim3(GSX_TOP_NT), 0, c->stream, c->lod_a, c->lod_b,
+        hipLaunchKernelGGL(k_octree_top, dim3(gsx_div_up(lv.start[top] * 8u, GSX_TOP_NT)), dim3(GSX_TOP_NT), 0, c->sel_stream, c->lod_a, c->lod_b,
                            c->lod_leaf, c->lod_child, c->lod_top_anc, lv.start[top], lv.start[top - 1u], top, m, thr,
                            static_cast<uint8_t>(match), c->lod_emit, c->lod_queue[top & 1u], c->lod_qcount);
         for (uint32_t l = top; l < c->lod_levels; ++l) {
             // (the queue's length is only known on the device: the grid covers the level, workgroups past the queue leave at once)
             const uint32_t width = lv.start[l + 1] - lv.start[l];
             if (width <= (256u << 10))
-                hipLaunchKernelGGL(k_octree_level<256>, dim3(gsx_div_up(width, 256)), dim3(256), 0, c->stream, c->lod_a, c->lod_b,
+                hipLaunchKernelGGL(k_octree_level<256>, dim3(gsx_div_up(width, 256)), dim3(256), 0, c->sel_stream, c->lod_a, c->lod_b,
                                    c->lod_leaf, c->lod_child, l, m, thr, static_cast<uint8_t>(match), c->lod_emit, c->lod_queue[l & 1u],
                                    c->lod_queue[(l + 1u) & 1u], c->lod_qcount);
             else
-                hipLaunchKernelGGL(k_octree_level<1024>, dim3(gsx_div_up(width, 1024)), dim3(1024), 0, c->stream, c->lod_a, c->lod_b,
+                hipLaunchKernelGGL(k_octree_level<1024>, dim3(gsx_div_up(width, 1024)), dim3(1024), 0, c->sel_stream, c->lod_a, c->lod_b,
                                    c->lod_leaf, c->lod_child, l, m, thr, static_cast<uint8_t>(match), c->lod_emit, c->lod_queue[l & 1u],
                                    c->lod_queue[(l + 1u) & 1u], c->lod_qcount);
         }
     } else {
         c->lod_stamp = 255u;            // the flags below overwrite the stamps
-        hipLaunchKernelGGL(k_octree_stop, dim3(gsx_div_up(n, 256)), dim3(256), 0, c->stream, c->lod_a, c->lod_b, c->lod_leaf, n,
+        hipLaunchKernelGGL(k_octree_stop, dim3(gsx_div_up(n, 256)), dim3(256), 0, c->sel_stream, c->lod_a, c->lod_b, c->lod_leaf, n,
                            m, thr, c->lod_stop);
-        hipLaunchKernelGGL(k_emit_flags, dim3(gsx_div_up(n, 256)), dim3(256), 0, c->stream, c->lod_stop, c->lod_parent, n,
+        hipLaunchKernelGGL(k_emit_flags, dim3(gsx_div_up(n, 256)), dim3(256), 0, c->sel_stream, c->lod_stop, c->lod_parent, n,
                            c->lod_emit);
     }
     const int rc = compact(c, n, match);
-    if (c->profiling) GSX_HIP(c, hipEventRecord(c->ev[EV_SEL1], c->stream));
+    if (c->profiling) GSX_HIP(c, hipEventRecord(c->ev[EV_SEL1], c->sel_stream));
     return rc;
 }
 
 int gsx_launch_select_hc(gsx_ctx* c, const float cam[3], float thr) {
     const uint32_t n = c->lod_nodes;
-    if (c->profiling) GSX_HIP(c, hipEventRecord(c->ev[EV_SEL0], c->stream));
+    if (c->profiling) GSX_HIP(c, hipEventRecord(c->ev[EV_SEL0], c->sel_stream));
     c->lod_stamp = 255u;
-    hipLaunchKernelGGL(k_hc_stop, dim3(gsx_div_up(n, 256)), dim3(256), 0, c->stream, c->lod_a, c->pos4, c->lod_leaf, n,
+    hipLaunchKernelGGL(k_hc_stop, dim3(gsx_div_up(n, 256)), dim3(256), 0, c->sel_stream, c->lod_a, c->pos4, c->lod_leaf, n,
                        cam[0], cam[1], cam[2], thr, c->lod_stop);
-    hipLaunchKernelGGL(k_emit_flags, dim3(gsx_div_up(n, 256)), dim3(256), 0, c->stream, c->lod_stop, c->lod_parent, n,
+    hipLaunchKernelGGL(k_emit_flags, dim3(gsx_div_up(n, 256)), dim3(256), 0, c->sel_stream, c->lod_stop, c->lod_parent, n,
                        c->lod_emit);
     const int rc = compact(c, n);
-    if (c->profiling) GSX_HIP(c, hipEventRecord(c->ev[EV_SEL1], c->stream));
+    if (c->profiling) GSX_HIP(c, hipEventRecord(c->ev[EV_SEL1], c->sel_stream));
     return rc;
 }
 
@@ -319,9 +319,9 @@ __global__ __launch_bounds__(256) void k_mark_list(const uint32_t* __restrict__ 
 int gsx_launch_sort_list(gsx_ctx* c, uint32_t m) {
     const uint32_t n = static_cast<uint32_t>(c->n);
     c->lod_stamp = 255u;
-    GSX_HIP(c, hipMemsetAsync(c->lod_emit, 0, (static_cast<uint64_t>(n) + 15) / 16 * 16, c->stream));
+    GSX_HIP(c, hipMemsetAsync(c->lod_emit, 0, (static_cast<uint64_t>(n) + 15) / 16 * 16, c->sel_stream));
     if (m > 0)
-        hipLaunchKernelGGL(k_mark_list, dim3(gsx_div_up(m, 256)), dim3(256), 0, c->stream, c->vals[0], m, n, c->lod_emit,
+        hipLaunchKernelGGL(k_mark_list, dim3(gsx_div_up(m, 256)), dim3(256), 0, c->sel_stream, c->vals[0], m, n, c->lod_emit,
                            c->flags);
     return compact(c, n);
 }

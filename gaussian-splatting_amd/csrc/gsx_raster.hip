@@ -894,6 +894,7 @@ int gsx_launch_render(gsx_ctx* c, const gsx_uniforms* u, uint32_t w, uint32_t h,
     hipLaunchKernelGGL(k_frame_init, dim3(gsx_div_up(n_tiles, 256)), dim3(256), 0, c->stream, c->ctl, c->m_dev, c->live_bits,
                        c->tile_state, vp.tiles_x, vp.tiles_y, c->aux);
     if (c->profiling) GSX_HIP(c, hipEventRecord(c->ev[EV_PROJ1], c->stream));
+    if (c->ev_frame_init && hipEventRecord(c->ev_frame_init, c->stream) == hipSuccess) c->frame_init_rec = true;   // m_dev may change behind this point
 
     // K4 + K5: near -> far iterations with geometrically growing rank windows.  Only as many ranks are scheduled
     // as recent frames needed before every tile was retired (plus a margin): what lies behind is hidden anyway, and if this

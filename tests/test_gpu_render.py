@@ -550,3 +550,56 @@ def test_render_into_caller_owned_target(gsx_fresh, pkg, oracle, synth):
     gsx.sync()
     band = buf[:nbytes].cpu().numpy().reshape(h, w, 4)
     assert np.array_equal(band[32:112], img[32:112]) and np.all(band[:32] == 9) and np.all(band[112:] == 9)
+
+
+@pytest.mark.parametrize("lod", [False, True])
+def test_two_stream_pipeline_matches_single_stream(gsx_fresh, pkg, oracle, synth, lod):
+    """The LOD cut and the depth sort of frame k+1 run on a second stream beside the binning / rasterizing of frame k
+    (option async_sort, default on).  Twelve frames of an orbit queued without a single read-back, each into its own slot of a
+    caller-owned buffer, must be byte-identical to the same twelve frames with everything on one stream - also with
+    profiling level 2 on, which moves every 4th sort to the main stream."""
+    import importlib
+    import torch
+    lodm = importlib.import_module("gaussian_splatting_amd.lod")
+    gsx = gsx_fresh
+    w, h, frames = 480, 270, 12
+    nbytes = w * h * 4
+    tree = None
+    if lod:
+        tree = lodm.build_octree(synth.clustered_cloud(300_000, seed=9))
+        tree.upload(gsx)
+    else:
+        gsx.upload(oracle.raw_to_splat(synth.clustered_cloud(300_000, seed=9)))
+    poses = []
+    for f in range(frames):
+        world, _ = oracle.orbit_world(4.0, (0.0, 1.0, 0.0), 2.0 * np.pi / 40.0, f)
+        view, proj, vp, cam = oracle.camera(world, 45.0, w / h)
+        poses.append((pkg.make_uniforms(proj, view), cam, vp))
+    buf = torch.zeros(frames * nbytes, dtype=torch.uint8, device="cuda:0")
+    torch.cuda.synchronize()
+
+    def run(async_on, level):
+        gsx.set_option("async_sort", async_on)
+        gsx.set_profiling(level)
+        buf.zero_()
+        torch.cuda.synchronize()
+        for f, (u, cam, vp) in enumerate(poses):
+            if lod:
+                gsx.select_octree(vp, 0.002, want_count=False)
+            gsx.sort(cam, download=False)
+            gsx.set_framebuffer_dev(buf.data_ptr() + f * nbytes, nbytes)
+            gsx.render(u, w, h, download=False)
+        gsx.set_framebuffer_dev(None)
+        gsx.sync()
+        return buf.cpu().numpy().reshape(frames, h, w, 4).copy()
+
+    ref = run(0, 0)
+    assert ref[..., :3].std() > 5 and not np.array_equal(ref[0], ref[6])
+    for level in (0, 2):
+        got = run(1, level)
+        for f in range(frames):
+            assert np.array_equal(got[f], ref[f]), (level, f)
+    gsx.set_profiling(0)
+    if tree is not None:
+        gsx.select_all()
+        tree.close()
