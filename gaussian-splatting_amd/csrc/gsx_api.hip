@@ -1,5 +1,6 @@
 // gsx_api.hip — the extern "C" entry points declared in include/gsx.h.
 #include <cstddef>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>

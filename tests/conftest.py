@@ -5,6 +5,11 @@ import sys
 import numpy as np
 import pytest
 
+try:                       # torch ships its own HIP / HSA runtime: when a test uses torch on the GPU, that runtime has to be the
+    import torch           # one the process loads first (libgsx then binds to it by soname); the other order leaves torch
+except ImportError:        # without a device ("No HIP GPUs are available")
+    torch = None
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 sys.path.insert(0, os.path.join(ROOT, "tests"))

@@ -559,7 +559,6 @@ def test_two_stream_pipeline_matches_single_stream(gsx_fresh, pkg, oracle, synth
     caller-owned buffer, must be byte-identical to the same twelve frames with everything on one stream - also with
     profiling level 2 on, which moves every 4th sort to the main stream."""
     import importlib
-    import torch
     lodm = importlib.import_module("gaussian_splatting_amd.lod")
     gsx = gsx_fresh
     w, h, frames = 480, 270, 12
@@ -575,23 +574,28 @@ def test_two_stream_pipeline_matches_single_stream(gsx_fresh, pkg, oracle, synth
         world, _ = oracle.orbit_world(4.0, (0.0, 1.0, 0.0), 2.0 * np.pi / 40.0, f)
         view, proj, vp, cam = oracle.camera(world, 45.0, w / h)
         poses.append((pkg.make_uniforms(proj, view), cam, vp))
-    buf = torch.zeros(frames * nbytes, dtype=torch.uint8, device="cuda:0")
-    torch.cuda.synchronize()
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    hip.hipMemset.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
+    hip.hipFree.argtypes = [C.c_void_p]
+    buf = C.c_void_p()
+    assert hip.hipMalloc(C.byref(buf), frames * nbytes) == 0
 
     def run(async_on, level):
         gsx.set_option("async_sort", async_on)
         gsx.set_profiling(level)
-        buf.zero_()
-        torch.cuda.synchronize()
+        gsx.sync()
+        assert hip.hipMemset(buf, 0, frames * nbytes) == 0
         for f, (u, cam, vp) in enumerate(poses):
             if lod:
                 gsx.select_octree(vp, 0.002, want_count=False)
             gsx.sort(cam, download=False)
-            gsx.set_framebuffer_dev(buf.data_ptr() + f * nbytes, nbytes)
+            gsx.set_framebuffer_dev(buf.value + f * nbytes, nbytes)
             gsx.render(u, w, h, download=False)
         gsx.set_framebuffer_dev(None)
         gsx.sync()
-        return buf.cpu().numpy().reshape(frames, h, w, 4).copy()
+        return _read_device(buf.value, frames * nbytes).reshape(frames, h, w, 4).copy()
 
     ref = run(0, 0)
     assert ref[..., :3].std() > 5 and not np.array_equal(ref[0], ref[6])
@@ -600,6 +604,7 @@ def test_two_stream_pipeline_matches_single_stream(gsx_fresh, pkg, oracle, synth
         for f in range(frames):
             assert np.array_equal(got[f], ref[f]), (level, f)
     gsx.set_profiling(0)
+    assert hip.hipFree(buf) == 0
     if tree is not None:
         gsx.select_all()
         tree.close()
