@@ -292,10 +292,12 @@ def main():
             if batcher is not None:
                 slot = batcher.slot(frame_no)
                 if fg is not None:
-                    g.set_framebuffer_dev(slot, fb_bytes)              # completes the previous frame into ITS slot first
+                    g.set_framebuffer_dev(slot, fb_bytes)              # (the frames already queued keep their own slots)
                 else:
                     g.set_framebuffer_dev(slot.data_ptr(), fb_bytes)
                 if frame_no:
+                    if bg is not None:
+                        g.stream()                                     # (orders the main stream, where torch gathers, behind the frames queued so far)
                     batcher.frame_done(frame_no - 1)                   # closes a batch every gather_batch frames
             g.render(uni, W, H, download=False)
         frame_no += 1
@@ -305,6 +307,8 @@ def main():
         batcher = fg or bg
         if batcher is not None and frame_no:
             g.set_framebuffer_dev(None)
+            if bg is not None:
+                g.stream()
             batcher.frame_done(frame_no - 1)
             batcher.finish()
 

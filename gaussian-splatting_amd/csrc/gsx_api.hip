@@ -55,7 +55,9 @@ int alloc_scene(gsx_ctx* c, uint64_t n) {
     if ((rc = dev_alloc(c, &c->sel_idx, n))) return rc;
     c->sel_cap = n;
     for (int b = 0; b < 2; ++b)
-        if ((rc = dev_alloc(c, &c->keys[b], n)) || (rc = dev_alloc(c, &c->vals[b], n)) || (rc = dev_alloc(c, &c->perm[b], n))) return rc;
+        if ((rc = dev_alloc(c, &c->keys[b], n)) || (rc = dev_alloc(c, &c->vals[b], n))) return rc;
+    for (int b = 0; b < GSX_PERM_RING; ++b)
+        if ((rc = dev_alloc(c, &c->perm[b], n))) return rc;
     c->sort_cap = n;
     c->sort_ws_words = gsx_sort_workspace_words(n);
     if ((rc = dev_alloc(c, &c->sort_ws, c->sort_ws_words))) return rc;
@@ -89,11 +91,12 @@ int gsx_create(int device, gsx_ctx** out) {
     if (hipSetDevice(device) != hipSuccess) return fail(GSX_E_HIP);
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return fail(GSX_E_HIP);
     if (hipStreamCreateWithFlags(&c->sort_stream, hipStreamNonBlocking) != hipSuccess) return fail(GSX_E_HIP);
-    if (hipEventCreateWithFlags(&c->ev_sorted, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_pre, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_frame_done[0], hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_frame_done[1], hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_frame_init, hipEventDisableTiming) != hipSuccess)
+    if (hipStreamCreateWithFlags(&c->parked.fstream, hipStreamNonBlocking) != hipSuccess) return fail(GSX_E_HIP);
+    c->fstream = c->stream;              // slot 0 queues its frames on the main stream
+    if (hipEventCreateWithFlags(&c->ev_sorted, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_pre, hipEventDisableTiming) != hipSuccess)
         return fail(GSX_E_HIP);
+    for (int b = 0; b < GSX_PERM_RING; ++b)
+        if (hipEventCreateWithFlags(&c->ev_frame_done[b], hipEventDisableTiming) != hipSuccess) return fail(GSX_E_HIP);
     c->sel_stream = c->stream;
     if (gsx_scratch_init(c, device) != GSX_OK) return fail(GSX_E_HIP);
     {
@@ -104,20 +107,24 @@ int gsx_create(int device, gsx_ctx** out) {
     }
     for (int i = 0; i < EV_COUNT; ++i)
         if (hipEventCreate(&c->ev[i]) != hipSuccess) return fail(GSX_E_HIP);
-    if (hipEventCreateWithFlags(&c->frame_ev, hipEventDisableTiming) != hipSuccess) return fail(GSX_E_HIP);
     for (int i = 0; i < GSX_SAMPLE_RING; ++i) {
         c->samp_pass[i] = -1;
         if (hipEventCreate(&c->samp_ev[i][0]) != hipSuccess || hipEventCreate(&c->samp_ev[i][1]) != hipSuccess) return fail(GSX_E_HIP);
     }
-    // control block and aux words: one allocation (aux GSX_AUX_OFFSET bytes in, on cache lines of its own) so that the
-    // frame's end needs a single device -> host copy
+    // per frame slot: control block and aux words in one allocation (aux GSX_AUX_OFFSET bytes in, on cache lines of its own) so
+    // that the frame's end needs a single device -> host copy
     static_assert(sizeof(GsxFrameCtl) <= GSX_AUX_OFFSET, "aux words must not share the control block's lines");
-    if (hipMalloc(reinterpret_cast<void**>(&c->ctl), GSX_AUX_OFFSET + 256) != hipSuccess) return fail(GSX_E_NOMEM);
-    c->aux = reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(c->ctl) + GSX_AUX_OFFSET);
-    if (hipMalloc(reinterpret_cast<void**>(&c->live_bits), GSX_MAX_TILES_Y * GSX_LIVE_ROW_WORDS * 4) != hipSuccess) return fail(GSX_E_NOMEM);
-    if (hipHostMalloc(reinterpret_cast<void**>(&c->ctl_host), GSX_AUX_OFFSET + 128, hipHostMallocDefault) != hipSuccess)
-        return fail(GSX_E_NOMEM);
-    c->aux_host = reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(c->ctl_host) + GSX_AUX_OFFSET);
+    for (GsxFrameSlot* sl : {static_cast<GsxFrameSlot*>(c), &c->parked}) {
+        if (hipEventCreateWithFlags(&sl->frame_ev, hipEventDisableTiming) != hipSuccess) return fail(GSX_E_HIP);
+        if (hipMalloc(reinterpret_cast<void**>(&sl->ctl), GSX_AUX_OFFSET + 256) != hipSuccess) return fail(GSX_E_NOMEM);
+        sl->aux = reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(sl->ctl) + GSX_AUX_OFFSET);
+        if (hipMalloc(reinterpret_cast<void**>(&sl->live_bits), GSX_MAX_TILES_Y * GSX_LIVE_ROW_WORDS * 4) != hipSuccess) return fail(GSX_E_NOMEM);
+        if (hipHostMalloc(reinterpret_cast<void**>(&sl->ctl_host), GSX_AUX_OFFSET + 128, hipHostMallocDefault) != hipSuccess)
+            return fail(GSX_E_NOMEM);
+        sl->aux_host = reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(sl->ctl_host) + GSX_AUX_OFFSET);
+    }
+    if (hipMalloc(reinterpret_cast<void**>(&c->m_perm), 64) != hipSuccess) return fail(GSX_E_NOMEM);
+    if (hipMemset(c->m_perm, 0, 64) != hipSuccess) return fail(GSX_E_HIP);
     if (hipMalloc(reinterpret_cast<void**>(&c->stat), GSX_STAT_BYTES) != hipSuccess) return fail(GSX_E_NOMEM);
     if (hipMalloc(reinterpret_cast<void**>(&c->m_dev), 16) != hipSuccess) return fail(GSX_E_NOMEM);
     if (hipMalloc(reinterpret_cast<void**>(&c->aabb_dev), 32) != hipSuccess) return fail(GSX_E_NOMEM);
@@ -136,19 +143,28 @@ int gsx_destroy(gsx_ctx* c) {
     if (!c) return GSX_E_INVALID;
     (void)hipSetDevice(c->device);
     c->frame_pending = false;
+    c->parked.frame_pending = false;
     if (c->sort_stream) (void)hipStreamSynchronize(c->sort_stream);
-    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->parked.fstream) (void)hipStreamSynchronize(c->parked.fstream);
+    if (c->fstream) (void)hipStreamSynchronize(c->fstream);
+    if (c->active_slot) gsx_slot_switch(c);          // slot 0 (the main stream's) back into the base
     dev_free(&c->pos4); dev_free(&c->geo);
-    dev_free(&c->sel_idx); dev_free(&c->m_dev);
+    dev_free(&c->sel_idx); dev_free(&c->m_dev); dev_free(&c->m_perm);
     dev_free(&c->lod_a); dev_free(&c->lod_b); dev_free(&c->lod_parent); dev_free(&c->lod_leaf); dev_free(&c->lod_child); dev_free(&c->lod_queue[0]); dev_free(&c->lod_queue[1]); dev_free(&c->lod_qcount); dev_free(&c->lod_top_anc);
     dev_free(&c->lod_stop); dev_free(&c->lod_emit); dev_free(&c->lod_block_sums);
-    for (int b = 0; b < 2; ++b) { dev_free(&c->keys[b]); dev_free(&c->vals[b]); dev_free(&c->perm[b]); dev_free(&c->pair_key[b]); dev_free(&c->pair_val[b]); }
-    dev_free(&c->sort_ws); dev_free(&c->aabb_dev); dev_free(&c->flags); dev_free(&c->pair_ws);
-    dev_free(&c->scan_block_sums); dev_free(&c->stat);
-    dev_free(&c->fb);
-    dev_free(&c->sub_off); dev_free(&c->rank_box); dev_free(&c->rank_rec); dev_free(&c->ctl); dev_free(&c->live_bits); dev_free(&c->tile_state); dev_free(&c->accum);
-    if (c->ctl_host) (void)hipHostFree(c->ctl_host);
-    if (c->frame_ev) (void)hipEventDestroy(c->frame_ev);
+    for (int b = 0; b < 2; ++b) { dev_free(&c->keys[b]); dev_free(&c->vals[b]); }
+    for (int b = 0; b < GSX_PERM_RING; ++b) dev_free(&c->perm[b]);
+    dev_free(&c->sort_ws); dev_free(&c->aabb_dev); dev_free(&c->flags);
+    dev_free(&c->stat);
+    for (GsxFrameSlot* sl : {static_cast<GsxFrameSlot*>(c), &c->parked}) {
+        for (int b = 0; b < 2; ++b) { dev_free(&sl->pair_key[b]); dev_free(&sl->pair_val[b]); }
+        dev_free(&sl->pair_ws); dev_free(&sl->scan_block_sums); dev_free(&sl->fb);
+        dev_free(&sl->sub_off); dev_free(&sl->rank_box); dev_free(&sl->rank_rec); dev_free(&sl->ctl); dev_free(&sl->live_bits);
+        dev_free(&sl->tile_state); dev_free(&sl->accum);
+        if (sl->ctl_host) { (void)hipHostFree(sl->ctl_host); sl->ctl_host = nullptr; }
+        if (sl->frame_ev) { (void)hipEventDestroy(sl->frame_ev); sl->frame_ev = nullptr; }
+    }
+    if (c->parked.fstream) (void)hipStreamDestroy(c->parked.fstream);
     for (int i = 0; i < GSX_SAMPLE_RING; ++i)
         for (int k = 0; k < 2; ++k)
             if (c->samp_ev[i][k]) (void)hipEventDestroy(c->samp_ev[i][k]);
@@ -156,7 +172,7 @@ int gsx_destroy(gsx_ctx* c) {
     if (c->flags_host) (void)hipHostFree(c->flags_host);
     for (int i = 0; i < EV_COUNT; ++i)
         if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
-    for (hipEvent_t e : {c->ev_sorted, c->ev_pre, c->ev_frame_done[0], c->ev_frame_done[1], c->ev_frame_init})
+    for (hipEvent_t e : {c->ev_sorted, c->ev_pre, c->ev_frame_done[0], c->ev_frame_done[1], c->ev_frame_done[2]})
         if (e) (void)hipEventDestroy(e);
     if (c->sort_stream) (void)hipStreamDestroy(c->sort_stream);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -189,6 +205,11 @@ int gsx_set_option(gsx_ctx* c, const char* name, uint64_t value) {
         c->opt_lod_walk = value ? 1 : 0;
     } else if (!std::strcmp(name, "async_sort")) {
         c->opt_async_sort = value ? 1 : 0;
+    } else if (!std::strcmp(name, "frames_in_flight")) {
+        if (value < 1 || value > 2) { c->err = "frames_in_flight must be 1 or 2"; return GSX_E_INVALID; }
+        int rc = set_device(c);
+        if (rc || (rc = gsx_frame_finish(c))) return rc;
+        c->opt_frames_in_flight = value;
     } else {
         c->err = std::string("unknown option: ") + name;
         return GSX_E_INVALID;
@@ -293,8 +314,8 @@ static int upload_common(gsx_ctx* c, const void* aos_dev, uint64_t n) {
     int rc;
     if ((rc = gsx_frame_finish(c))) return rc;
     c->main_dirty = true;
-    c->frame_done_rec[0] = c->frame_done_rec[1] = false;
-    c->frame_init_rec = false;
+    for (bool& r : c->frame_done_rec) r = false;
+    c->sorted_rec = false;
     if ((rc = alloc_scene(c, n))) return rc;
     c->n = n;
     GSX_HIP(c, hipMemsetAsync(c->flags, 0, sizeof(GsxDevFlags), c->stream));
@@ -470,7 +491,7 @@ int gsx_set_lod_hc(gsx_ctx* c, const gsx_hc_flat* f) {
 }
 
 // A camera-dependent cut feeds the next sort and nothing else, so it is queued where that sort runs: on the sort stream,
-// beside the frame in flight, which has no use for the selection once its first kernel has read the size (ev_frame_init).
+// beside the frames in flight (they read the size of THEIR selection from a word of their own, gsx_ctx::m_perm).
 // Returns the stream in c->sel_stream.  Without the second stream (or with every stage bracketed) the cut waits for the
 // frame and goes to the main stream.
 static int begin_select(gsx_ctx* c) {
@@ -488,7 +509,6 @@ static int begin_select(gsx_ctx* c) {
         c->main_dirty = false;
     }
     if (c->pre_wait) { GSX_HIP(c, hipStreamWaitEvent(st, c->ev_pre, 0)); c->pre_wait = false; }
-    if (c->frame_init_rec) GSX_HIP(c, hipStreamWaitEvent(st, c->ev_frame_init, 0));
     return GSX_OK;
 }
 
@@ -556,7 +576,12 @@ int gsx_sort(gsx_ctx* c, const float cam_pos[3], uint32_t* idx_out_host) {
     if (rc) return rc;
     // A frame in flight reads perm[perm_cur]; this sort writes the other buffer, so it is queued behind that frame without
     // waiting for it.  Only a frame that still draws from the target buffer (two sorts without a render between) must end first.
-    if (c->frame_pending && c->frame.sorted == c->perm[c->perm_cur ^ 1u] && (rc = gsx_frame_finish(c))) return rc;
+    {
+        const uint32_t* target = c->perm[(c->perm_cur + 1u) % GSX_PERM_RING];
+        if (((c->frame_pending && c->frame.sorted == target) || (c->parked.frame_pending && c->parked.frame.sorted == target)) &&
+            (rc = gsx_frame_finish(c)))
+            return rc;
+    }
     c->cam[0] = cam_pos[0]; c->cam[1] = cam_pos[1]; c->cam[2] = cam_pos[2];
     if ((rc = gsx_launch_sort(c))) return rc;
     c->ev_recorded[EV_SORT1] = c->profiling;
@@ -620,7 +645,16 @@ int gsx_render(gsx_ctx* c, const gsx_uniforms* u, uint32_t width, uint32_t heigh
     if (!c->sorted_valid) { c->err = "gsx_render before gsx_sort"; return GSX_E_STATE; }
     int rc = set_device(c);
     if (rc) return rc;
-    if ((rc = gsx_frame_finish(c))) return rc;
+    if (c->opt_frames_in_flight >= 2 && !c->profiling && c->parked.fstream) {
+        // two frames in flight: this frame takes the slot of the frame before the last one (long finished, as a rule) and is
+        // queued beside the last one, which the host does not wait for
+        if (c->frame_pending) gsx_slot_switch(c);
+        if ((rc = gsx_frame_finish_active(c))) return rc;
+    } else if ((rc = gsx_frame_finish(c))) {
+        return rc;
+    }
+    if (c->sorted_rec) GSX_HIP(c, hipStreamWaitEvent(c->fstream, c->ev_sorted, 0));   // the permutation (sorted on another stream, maybe)
+    if (c->fstream == c->stream) c->sort_join_pending = false;
     if ((rc = gsx_launch_render(c, u, width, height, y0, y1))) return rc;
     c->ev_recorded[EV_RAST1] = c->profiling;
     if (rgba8_out_host) {
@@ -672,7 +706,7 @@ int gsx_set_framebuffer_dev(gsx_ctx* c, void* rgba8_dev, uint64_t capacity_bytes
     if (!c || (rgba8_dev && capacity_bytes == 0)) return GSX_E_INVALID;
     int rc = set_device(c);
     if (rc) return rc;
-    if ((rc = gsx_frame_finish(c))) return rc;     // the queued frame completes into the target it was started on
+    // (frames already queued keep the target they were started on: every frame slot remembers its own)
     c->fb_ext = static_cast<uint8_t*>(rgba8_dev);
     c->fb_ext_cap = rgba8_dev ? capacity_bytes : 0;
     return GSX_OK;
@@ -680,6 +714,13 @@ int gsx_set_framebuffer_dev(gsx_ctx* c, void* rgba8_dev, uint64_t capacity_bytes
 
 int gsx_get_stream(gsx_ctx* c, void** hip_stream) {
     if (!c || !hip_stream) return GSX_E_INVALID;
+    int rc = set_device(c);
+    if (rc) return rc;
+    // frames may be in flight on the library's other streams: what the caller queues on the main stream from now on runs
+    // behind every frame and sort queued so far
+    gsx_join_sort(c);
+    for (GsxFrameSlot* sl : {static_cast<GsxFrameSlot*>(c), &c->parked})
+        if (sl->frame_pending && sl->fstream != c->stream) GSX_HIP(c, hipStreamWaitEvent(c->stream, sl->frame_ev, 0));
     *hip_stream = static_cast<void*>(c->stream);
     return GSX_OK;
 }

@@ -10,6 +10,7 @@
 
 #define GSX_WAVE 64
 #define GSX_SAMPLE_RING 32
+#define GSX_PERM_RING 3           // permutation buffers: two frames in flight read two of them while the next sort fills the third
 #define GSX_SAMPLE_WHOLE 4
 #define GSX_SAMPLE_EVERY 4u       // profiling level 2 samples every 4th sort
 #define GSX_LOD_MAX_LEVELS 48
@@ -94,7 +95,48 @@ struct GsxGeo {
     float4 color;   // linear rgb + alpha
 };
 
-struct gsx_ctx {
+// Everything one frame in flight owns.  The context holds two: frame k+1 is binned and rasterized on the other slot's stream
+// while frame k is still running (the kernels of one frame leave much of the GPU idle: single-workgroup scans, dependent
+// launches, the rasterizer's tail), and the host never waits for frame k before it queues frame k+1.  gsx_ctx derives from
+// the ACTIVE slot, so the frame loop's code reads c->ctl, c->pair_key ... as before; gsx_slot_switch swaps the two.
+struct GsxFrameSlot {
+    hipStream_t fstream = nullptr;     // the stream this slot's frames are queued on (slot 0: the context's main stream)
+    uint64_t frame_seq = 0;            // launch order of the frame in this slot (older frames are finished first)
+    uint32_t* scan_block_sums = nullptr;
+    uint64_t rank_cap = 0;
+    uint16_t* pair_key[2] = {nullptr, nullptr};
+    uint32_t* pair_val[2] = {nullptr, nullptr};
+    uint64_t pair_cap = 0;
+    uint8_t* fb = nullptr;             // RGBA8 width*height (the library's own framebuffer of this slot)
+    uint64_t fb_cap = 0;
+    uint8_t* fb_cur = nullptr;         // where the slot's queued / last frame was rendered
+    uint32_t fb_w = 0, fb_h = 0;
+    uint32_t* pair_ws = nullptr;       // radix workspace of the pair sort
+    uint64_t pair_ws_words = 0;
+    uint64_t pair_alloc = 0;           // allocated pairs per buffer (pair_cap = budget in use <= pair_alloc)
+    uint32_t* sub_off = nullptr;       // per count block: 17 in-block pair offsets (64-rank boundaries)
+    uint64_t sub_off_cap = 0;
+    uint32_t* rank_box = nullptr;      // per rank of the iteration's window: packed tile box (k_chunk_count -> k_chunk_emit)
+    float4* rank_rec = nullptr;        // per rank of the window: 48-B record (centre/extents, uv matrix, colour) for k_raster
+    uint64_t rank_box_cap = 0, rank_rec_cap = 0;
+    GsxFrameCtl* ctl = nullptr;
+    GsxFrameCtl* ctl_host = nullptr;   // pinned copy read after the frame
+    // aux[0] = cursor of the running iteration (plain data), aux[16] = ranks from the near end consumed by the tiles
+    // retired so far (atomicMax), aux[32] = pair count of the running iteration (second 128-byte line: never an atomic).  Kept OFF the control block's cache line: that line is hammered by returnless
+    // atomics while tiles retire, and any load from it then queues behind them (measured: raster 3x slower).
+    uint32_t* aux = nullptr;
+    uint32_t* aux_host = nullptr;      // pinned, 32 words
+    uint32_t* live_bits = nullptr;     // GSX_MAX_TILES_Y x GSX_LIVE_ROW_WORDS: tiles still unsaturated
+    uint32_t* tile_state = nullptr;    // per tile: 0 untouched, 1 accumulators valid, 2 retired
+    uint64_t tile_state_cap = 0;
+    float4* accum = nullptr;           // per tile x 256 pixels: (r, g, b, transmittance)
+    uint64_t accum_cap = 0;
+    GsxFrameState frame;
+    hipEvent_t frame_ev = nullptr;
+    bool frame_pending = false;
+};
+
+struct gsx_ctx : GsxFrameSlot {
     int device = 0;
     hipStream_t stream = nullptr;
     std::string err;
@@ -155,8 +197,9 @@ struct gsx_ctx {
     // The last radix pass writes into perm[perm_cur ^ 1] and then flips perm_cur: a frame still in flight (and any
     // continuation iterations gsx_frame_finish queues for it later) keeps reading the other buffer, so the next
     // frame's sort can be queued without waiting for the previous frame.
-    uint32_t* perm[2] = {nullptr, nullptr};
-    uint32_t perm_cur = 0;             // perm[perm_cur] holds the latest permutation
+    uint32_t* perm[GSX_PERM_RING] = {};
+    uint32_t perm_cur = 0;             // perm[perm_cur] holds the latest permutation; the next sort writes perm[(perm_cur + 1) % GSX_PERM_RING]
+    uint32_t* m_perm = nullptr;        // GSX_PERM_RING device words: size of the selection each permutation was sorted from
     uint32_t sort_passes = 0;
     bool sort_gated = false;   // the latest depth sort queued a gated top-digit pass (counted in sort_passes)
     uint32_t sort_slots = 1024, pair_slots = 1024;   // resident workgroups of the scatter kernels (CUs x blocks/CU)
@@ -168,41 +211,14 @@ struct gsx_ctx {
     GsxDevFlags* flags = nullptr;
     GsxDevFlags* flags_host = nullptr; // pinned
 
-    // raster
-    uint32_t* scan_block_sums = nullptr;
-    uint64_t rank_cap = 0;
-    uint16_t* pair_key[2] = {nullptr, nullptr};
-    uint32_t* pair_val[2] = {nullptr, nullptr};
-    uint64_t pair_cap = 0;
-    uint8_t* fb = nullptr;             // RGBA8 width*height (the library's own framebuffer)
-    uint64_t fb_cap = 0;
-    uint8_t* fb_ext = nullptr;         // caller-owned render target (gsx_set_framebuffer_dev), nullptr = use fb
+    // raster: the per-frame state lives in the GsxFrameSlot base (the ACTIVE slot); `parked` is the other slot
+    GsxFrameSlot parked;
+    uint32_t active_slot = 0;          // which physical slot the base members currently hold
+    uint64_t frame_counter = 0;
+    uint8_t* fb_ext = nullptr;         // caller-owned render target of the frames launched from now on (gsx_set_framebuffer_dev), nullptr = the slot's own
     uint64_t fb_ext_cap = 0;
-    uint8_t* fb_cur = nullptr;         // where the queued / last frame was rendered
-    uint32_t fb_w = 0, fb_h = 0;
-    uint32_t* pair_ws = nullptr;       // radix workspace of the pair sort
-    uint64_t pair_ws_words = 0;
-    uint64_t pair_alloc = 0;           // allocated pairs per buffer (pair_cap = budget in use <= pair_alloc)
     uint64_t pair_grown = 0;           // budget a frame had to grow to (kept for later frames)
-    uint32_t* sub_off = nullptr;       // per count block: 17 in-block pair offsets (64-rank boundaries)
-    uint64_t sub_off_cap = 0;
-    uint32_t* rank_box = nullptr;      // per rank of the iteration's window: packed tile box (k_chunk_count -> k_chunk_emit)
-    float4* rank_rec = nullptr;        // per rank of the window: 48-B record (centre/extents, uv matrix, colour) for k_raster
-    uint64_t rank_box_cap = 0, rank_rec_cap = 0;
-    GsxFrameCtl* ctl = nullptr;
-    GsxFrameCtl* ctl_host = nullptr;   // pinned copy read after the frame
-    // aux[0] = cursor of the running iteration (plain data), aux[16] = ranks from the near end consumed by the tiles
-    // retired so far (atomicMax), aux[32] = pair count of the running iteration (second 128-byte line: never an atomic).  Kept OFF the control block's cache line: that line is hammered by returnless
-    // atomics while tiles retire, and any load from it then queues behind them (measured: raster 3x slower).
-    uint32_t* aux = nullptr;
-    uint32_t* aux_host = nullptr;      // pinned, 32 words
     unsigned long long* stat = nullptr;   // GSX_STAT_BYTES of sharded counters: [shard*16 + 0] (wave, splat) shades, [+1] pixels blended
-    uint32_t* live_bits = nullptr;     // GSX_MAX_TILES_Y x GSX_LIVE_ROW_WORDS: tiles still unsaturated
-    uint32_t* tile_state = nullptr;    // per tile: 0 untouched, 1 accumulators valid, 2 retired
-    uint64_t tile_state_cap = 0;
-    float4* accum = nullptr;           // per tile x 256 pixels: (r, g, b, transmittance)
-    uint64_t accum_cap = 0;
-    GsxFrameState frame;
     // ranks (from the near end) earlier frames needed before every tile was retired; ~0u = the whole selection
     uint32_t need_hist[8] = {};
     uint32_t need_pos = 0;             // frames recorded so far (ring position = need_pos % 8)
@@ -211,8 +227,6 @@ struct gsx_ctx {
     bool have_last_cam = false;
     bool rest_merged = false;          // the last schedule took everything behind the first window in one iteration
     float density0 = 0.0f;             // (tile, splat) pairs per rank in the last frame's first window (0 = unknown)
-    hipEvent_t frame_ev = nullptr;
-    bool frame_pending = false;
     // tuning (gsx_set_option); 0 = automatic
     uint64_t opt_pair_budget = 0, opt_chunk_first = 0, opt_chunk_growth = 0, opt_no_history = 0, opt_lod_walk = 0;
     // The depth sort of frame k+1 runs on a stream of its own, beside the binning / rasterizing of frame k (it writes the
@@ -224,10 +238,10 @@ struct gsx_ctx {
     uint64_t opt_async_sort = 1;
     hipStream_t sort_stream = nullptr;
     hipStream_t sel_stream = nullptr;     // where the selection kernels of the current call are queued (main or sort stream)
-    hipEvent_t ev_frame_init = nullptr;   // main stream: the frame in flight has read the selection's size (k_frame_init)
-    bool frame_init_rec = false;
-    hipEvent_t ev_sorted = nullptr, ev_pre = nullptr, ev_frame_done[2] = {nullptr, nullptr};
-    bool frame_done_rec[2] = {false, false};
+    hipEvent_t ev_sorted = nullptr, ev_pre = nullptr, ev_frame_done[GSX_PERM_RING] = {};
+    bool frame_done_rec[GSX_PERM_RING] = {};
+    bool sorted_rec = false;              // ev_sorted has been recorded (behind the latest sort, on whichever stream it ran)
+    uint64_t opt_frames_in_flight = 2;
     bool sort_join_pending = false;      // a sort was queued on sort_stream and the main stream has not waited for it yet
     bool main_dirty = true;              // the main stream holds work the next sort must see (selection, upload): record ev_pre
     bool pre_wait = false;               // ev_pre is recorded and the sort stream has not waited for it yet
@@ -290,4 +304,6 @@ int gsx_launch_sort_list(gsx_ctx* c, uint32_t m); // ascending re-order of an ex
 int gsx_launch_render(gsx_ctx* c, const gsx_uniforms* u, uint32_t w, uint32_t h, uint32_t y0, uint32_t y1);
 void gsx_sample_drain(gsx_ctx* c, uint32_t slot);   // folds a finished level-2 sample into samp_sum_ms / samp_n
 void gsx_join_sort(gsx_ctx* c);                  // main stream waits for the sort stream's latest sort (no host wait)
-int gsx_frame_finish(gsx_ctx* c);                // waits for the queued frame; runs extra iterations if ranks are left
+int gsx_frame_finish(gsx_ctx* c);                // waits for every queued frame (oldest first); runs extra iterations if ranks are left
+int gsx_frame_finish_active(gsx_ctx* c);         // the same for the active slot's frame only
+void gsx_slot_switch(gsx_ctx* c);                // the other frame slot becomes the active one

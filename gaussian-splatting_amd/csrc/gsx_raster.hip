@@ -23,6 +23,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <utility>
 
 #include "gsx_internal.h"
 #include "gsx_radix.hpp"
@@ -761,15 +762,15 @@ static int launch_iteration(gsx_ctx* c, uint32_t iter, uint32_t window, bool fir
     const uint32_t nb = gsx_div_up(window, GSX_BIN_TILE);
     const uint32_t budget = static_cast<uint32_t>(c->pair_cap);
     if (nb > 0) {
-        hipLaunchKernelGGL(k_chunk_count, dim3(nb), dim3(GSX_CNT_NT), 0, c->stream, c->ctl, iter, window, sorted, c->geo,
+        hipLaunchKernelGGL(k_chunk_count, dim3(nb), dim3(GSX_CNT_NT), 0, c->fstream, c->ctl, iter, window, sorted, c->geo,
                            c->live_bits, vp, c->scan_block_sums, c->sub_off, c->rank_box, c->rank_rec);
-        hipLaunchKernelGGL(k_chunk_scan, dim3(1), dim3(1024), 0, c->stream, c->ctl, iter, window, nb, c->scan_block_sums, budget, c->aux);
+        hipLaunchKernelGGL(k_chunk_scan, dim3(1), dim3(1024), 0, c->fstream, c->ctl, iter, window, nb, c->scan_block_sums, budget, c->aux);
         // slot-parallel: one wave per GSX_EMIT_SLICE pairs.  The pair count is only known on the device (a window of a few
         // thousand huge splats can fill the whole budget), so the grid is sized for the budget; surplus waves exit at once.
         uint32_t emit_grid = gsx_div_up(gsx_div_up(c->pair_cap, GSX_EMIT_SLICE), GSX_BIN_NT / 64);
         if (emit_grid > 4096u) emit_grid = 4096u;
         if (emit_grid < 1u) emit_grid = 1u;
-        hipLaunchKernelGGL(k_chunk_emit, dim3(emit_grid), dim3(GSX_BIN_NT), 0, c->stream, c->ctl, vp.tiles_x, c->scan_block_sums,
+        hipLaunchKernelGGL(k_chunk_emit, dim3(emit_grid), dim3(GSX_BIN_NT), 0, c->fstream, c->ctl, vp.tiles_x, c->scan_block_sums,
                            c->sub_off, c->rank_box, c->pair_key[0], c->pair_val[0]);
     }
     // stable sort of the iteration's pairs by tile id; the pair count stays on the device
@@ -784,34 +785,34 @@ static int launch_iteration(gsx_ctx* c, uint32_t iter, uint32_t window, bool fir
     uint32_t* totals = cnt + static_cast<uint64_t>(GSX_RADIX_MAX_DIGITS) * cols;
     int cur = 0;
     for (int p = 0; p < plan.n_passes; ++p) {
-        hipLaunchKernelGGL((k_radix_hist<uint16_t, GSX_PAIR_NT>), dim3(g), dim3(GSX_PAIR_NT), 0, c->stream, c->pair_key[cur],
+        hipLaunchKernelGGL((k_radix_hist<uint16_t, GSX_PAIR_NT>), dim3(g), dim3(GSX_PAIR_NT), 0, c->fstream, c->pair_key[cur],
                            count_ptr, plan.shift[p], plan.bits[p], cnt, static_cast<uint32_t>(GSX_PAIR_TILE), cols);
-        hipLaunchKernelGGL((k_radix_scan<0>), dim3(1u << plan.bits[p]), dim3(256), 0, c->stream, cnt, count_ptr,
+        hipLaunchKernelGGL((k_radix_scan<0>), dim3(1u << plan.bits[p]), dim3(256), 0, c->fstream, cnt, count_ptr,
                            static_cast<uint32_t>(GSX_PAIR_TILE), cols, totals);
-        hipLaunchKernelGGL((k_radix_scatter<uint16_t, GSX_PAIR_NT, GSX_PAIR_IPT, false>), dim3(g), dim3(GSX_PAIR_NT), 0, c->stream,
+        hipLaunchKernelGGL((k_radix_scatter<uint16_t, GSX_PAIR_NT, GSX_PAIR_IPT, false>), dim3(g), dim3(GSX_PAIR_NT), 0, c->fstream,
                            c->pair_key[cur], c->pair_val[cur], c->pair_key[cur ^ 1], c->pair_val[cur ^ 1], count_ptr, plan.shift[p],
                            plan.bits[p], cnt, totals, cols);
         cur ^= 1;
     }
-    if (c->profiling && iter < GSX_MAX_SCHED && !f.continuing) GSX_HIP(c, hipEventRecord(c->ev[EV_IT0 + 2 * iter], c->stream));
+    if (c->profiling && iter < GSX_MAX_SCHED && !f.continuing) GSX_HIP(c, hipEventRecord(c->ev[EV_IT0 + 2 * iter], c->fstream));
     const uint32_t fi = first ? 1u : 0u;
     const bool count = c->profiling && c->stat != nullptr;
 #define GSX_LAUNCH_RASTER(M, CNT)                                                                                                       \
-    hipLaunchKernelGGL((k_raster<M, CNT>), dim3(f.n_tiles), dim3(GSX_RASTER_NT), 0, c->stream, c->pair_key[cur], c->pair_val[cur],    \
+    hipLaunchKernelGGL((k_raster<M, CNT>), dim3(f.n_tiles), dim3(GSX_RASTER_NT), 0, c->fstream, c->pair_key[cur], c->pair_val[cur],    \
                        c->rank_rec, iter, vp, fi, c->tile_state, c->live_bits, c->accum, c->ctl, c->aux, c->fb_cur, c->stat)
     if (f.mode == 0) { if (count) GSX_LAUNCH_RASTER(0, true); else GSX_LAUNCH_RASTER(0, false); }
     else if (f.mode == 1) { if (count) GSX_LAUNCH_RASTER(1, true); else GSX_LAUNCH_RASTER(1, false); }
     else { if (count) GSX_LAUNCH_RASTER(2, true); else GSX_LAUNCH_RASTER(2, false); }
 #undef GSX_LAUNCH_RASTER
-    if (c->profiling && iter < GSX_MAX_SCHED && !f.continuing) GSX_HIP(c, hipEventRecord(c->ev[EV_IT0 + 2 * iter + 1], c->stream));
+    if (c->profiling && iter < GSX_MAX_SCHED && !f.continuing) GSX_HIP(c, hipEventRecord(c->ev[EV_IT0 + 2 * iter + 1], c->fstream));
     return GSX_OK;
 }
 
 // Everything queued so far for the frame in flight reads permutation buffer b: the sort that overwrites b next waits for this.
 static void gsx_mark_frame_done(gsx_ctx* c) {
-    const uint32_t b = c->frame.sorted == c->perm[1] ? 1u : 0u;
-    if (!c->ev_frame_done[b]) return;
-    if (hipEventRecord(c->ev_frame_done[b], c->stream) == hipSuccess) c->frame_done_rec[b] = true;
+    for (uint32_t b = 0; b < GSX_PERM_RING; ++b)
+        if (c->frame.sorted == c->perm[b] && c->ev_frame_done[b] && hipEventRecord(c->ev_frame_done[b], c->fstream) == hipSuccess)
+            c->frame_done_rec[b] = true;
 }
 
 int gsx_launch_render(gsx_ctx* c, const gsx_uniforms* u, uint32_t w, uint32_t h, uint32_t y0, uint32_t y1) {
@@ -857,7 +858,7 @@ int gsx_launch_render(gsx_ctx* c, const gsx_uniforms* u, uint32_t w, uint32_t h,
     } else {
         if ((rc = ensure(c, &c->fb, &c->fb_cap, static_cast<uint64_t>(w) * h * 4)) != GSX_OK) return rc;
         if (c->fb_w != w || c->fb_h != h || c->fb_cur != c->fb) {
-            GSX_HIP(c, hipMemsetAsync(c->fb, 0, static_cast<uint64_t>(w) * h * 4, c->stream));
+            GSX_HIP(c, hipMemsetAsync(c->fb, 0, static_cast<uint64_t>(w) * h * 4, c->fstream));
             c->fb_w = w; c->fb_h = h;
         }
         c->fb_cur = c->fb;
@@ -889,12 +890,11 @@ int gsx_launch_render(gsx_ctx* c, const gsx_uniforms* u, uint32_t w, uint32_t h,
     f.continuing = false;
 
     // (K3, the projection, runs inside k_chunk_count on the ranks each iteration reaches)
-    if (c->profiling && c->stat) GSX_HIP(c, hipMemsetAsync(c->stat, 0, GSX_STAT_BYTES, c->stream));
-    if (c->profiling) GSX_HIP(c, hipEventRecord(c->ev[EV_PROJ0], c->stream));
-    hipLaunchKernelGGL(k_frame_init, dim3(gsx_div_up(n_tiles, 256)), dim3(256), 0, c->stream, c->ctl, c->m_dev, c->live_bits,
+    if (c->profiling && c->stat) GSX_HIP(c, hipMemsetAsync(c->stat, 0, GSX_STAT_BYTES, c->fstream));
+    if (c->profiling) GSX_HIP(c, hipEventRecord(c->ev[EV_PROJ0], c->fstream));
+    hipLaunchKernelGGL(k_frame_init, dim3(gsx_div_up(n_tiles, 256)), dim3(256), 0, c->fstream, c->ctl, c->m_perm + c->perm_cur, c->live_bits,
                        c->tile_state, vp.tiles_x, vp.tiles_y, c->aux);
-    if (c->profiling) GSX_HIP(c, hipEventRecord(c->ev[EV_PROJ1], c->stream));
-    if (c->ev_frame_init && hipEventRecord(c->ev_frame_init, c->stream) == hipSuccess) c->frame_init_rec = true;   // m_dev may change behind this point
+    if (c->profiling) GSX_HIP(c, hipEventRecord(c->ev[EV_PROJ1], c->fstream));
 
     // K4 + K5: near -> far iterations with geometrically growing rank windows.  Only as many ranks are scheduled
     // as recent frames needed before every tile was retired (plus a margin): what lies behind is hidden anyway, and if this
@@ -954,19 +954,44 @@ int gsx_launch_render(gsx_ctx* c, const gsx_uniforms* u, uint32_t w, uint32_t h,
         ++n_iters;
     } while (covered < need);
     f.n_iters = n_iters;
-    GSX_HIP(c, hipMemcpyAsync(c->ctl_host, c->ctl, GSX_AUX_OFFSET + 128, hipMemcpyDeviceToHost, c->stream));   // control block + aux
-    GSX_HIP(c, hipEventRecord(c->frame_ev, c->stream));
+    GSX_HIP(c, hipMemcpyAsync(c->ctl_host, c->ctl, GSX_AUX_OFFSET + 128, hipMemcpyDeviceToHost, c->fstream));   // control block + aux
+    GSX_HIP(c, hipEventRecord(c->frame_ev, c->fstream));
     gsx_mark_frame_done(c);
+    c->frame_seq = ++c->frame_counter;
     c->frame_pending = true;
-    if (c->profiling) GSX_HIP(c, hipEventRecord(c->ev[EV_RAST1], c->stream));
+    if (c->profiling) GSX_HIP(c, hipEventRecord(c->ev[EV_RAST1], c->fstream));
     GSX_HIP(c, hipGetLastError());
     return GSX_OK;
 }
 
 // Waits for the frame queued by gsx_launch_render and, if the device could not fit every rank into
 // the scheduled iterations (pair budget hit), keeps running iterations until the cursor reaches m.
+void gsx_slot_switch(gsx_ctx* c) {
+    GsxFrameSlot& a = *c;
+    std::swap(a, c->parked);
+    c->active_slot ^= 1u;
+}
+
+// Every queued frame, oldest first; the active slot is the same afterwards as before.
 int gsx_frame_finish(gsx_ctx* c) {
     gsx_join_sort(c);      // whatever the caller queues next may read the permutation or rewrite the sort's inputs
+    int rc = GSX_OK;
+    if (c->parked.frame_pending && (!c->frame_pending || c->parked.frame_seq < c->frame_seq)) {
+        gsx_slot_switch(c);
+        rc = gsx_frame_finish_active(c);
+        gsx_slot_switch(c);
+        if (rc) return rc;
+    }
+    if ((rc = gsx_frame_finish_active(c))) return rc;
+    if (c->parked.frame_pending) {
+        gsx_slot_switch(c);
+        rc = gsx_frame_finish_active(c);
+        gsx_slot_switch(c);
+    }
+    return rc;
+}
+
+int gsx_frame_finish_active(gsx_ctx* c) {
     if (!c->frame_pending) return GSX_OK;
     GSX_HIP(c, hipEventSynchronize(c->frame_ev));
     GsxFrameState& f = c->frame;
@@ -994,12 +1019,12 @@ int gsx_frame_finish(gsx_ctx* c) {
         }
         // restart the cursor ring at slot 0 and run one more iteration over everything that is left
         const uint32_t zero = 0;
-        GSX_HIP(c, hipMemcpyAsync(&c->ctl->cursor[0], &c->ctl->cursor[last], 4, hipMemcpyDeviceToDevice, c->stream));
-        GSX_HIP(c, hipMemcpyAsync(&c->ctl->stall, &zero, 4, hipMemcpyHostToDevice, c->stream));
+        GSX_HIP(c, hipMemcpyAsync(&c->ctl->cursor[0], &c->ctl->cursor[last], 4, hipMemcpyDeviceToDevice, c->fstream));
+        GSX_HIP(c, hipMemcpyAsync(&c->ctl->stall, &zero, 4, hipMemcpyHostToDevice, c->fstream));
         if ((rc = launch_iteration(c, 0, h.m - cur, false)) != GSX_OK) { c->frame_pending = false; return rc; }
-        GSX_HIP(c, hipMemcpyAsync(c->ctl_host, c->ctl, GSX_AUX_OFFSET + 128, hipMemcpyDeviceToHost, c->stream));
+        GSX_HIP(c, hipMemcpyAsync(c->ctl_host, c->ctl, GSX_AUX_OFFSET + 128, hipMemcpyDeviceToHost, c->fstream));
         gsx_mark_frame_done(c);
-        GSX_HIP(c, hipStreamSynchronize(c->stream));
+        GSX_HIP(c, hipStreamSynchronize(c->fstream));
         last = 1;
     }
     {

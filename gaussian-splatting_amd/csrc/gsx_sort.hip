@@ -319,7 +319,7 @@ int gsx_launch_sort(gsx_ctx* c) {
     sb.vals[0] = c->vals[0]; sb.vals[1] = c->vals[1];
     sb.ws = c->sort_ws;
     sb.ws_words = c->sort_ws_words;
-    const uint32_t target = c->perm_cur ^ 1u;
+    const uint32_t target = (c->perm_cur + 1u) % GSX_PERM_RING;
     sb.result = c->perm[target];
     sb.with_events = true;
     // (with every stage bracketed by events - profiling level 1 - the stages run one after another on the main stream, and so
@@ -337,21 +337,25 @@ int gsx_launch_sort(gsx_ctx* c) {
         // ev_pre: the point of the main stream this sort must be behind (selection / upload, or a sort that ran on the main
         // stream itself - a sampled one - and used the same key / value / count arrays)
         if (c->pre_wait) { GSX_HIP(c, hipStreamWaitEvent(st, c->ev_pre, 0)); c->pre_wait = false; }
-        // the last frame that drew from the buffer this sort overwrites (the frame before the one in flight)
-        if (c->frame_done_rec[target]) GSX_HIP(c, hipStreamWaitEvent(st, c->ev_frame_done[target], 0));
     } else {
         gsx_join_sort(c);                // behind the sort stream's latest sort: same arrays
     }
+    // the last frame that drew from the buffer this sort overwrites (three buffers: the frame before the two that may be in flight)
+    if (c->frame_done_rec[target]) GSX_HIP(c, hipStreamWaitEvent(st, c->ev_frame_done[target], 0));
     const int rc = launch_sort_in(c, sb, st);
     if (rc != GSX_OK) return rc;
+    // the frame drawn from this permutation reads the selection's size from a word of its own: the next selection may
+    // overwrite m_dev as soon as this sort is done
+    GSX_HIP(c, hipMemcpyAsync(c->m_perm + target, c->m_dev, sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
+    GSX_HIP(c, hipEventRecord(c->ev_sorted, st));   // what a frame's stream waits for before it draws this permutation
+    c->sorted_rec = true;
     if (async) {
-        GSX_HIP(c, hipEventRecord(c->ev_sorted, st));
         c->sort_join_pending = true;
     } else if (c->sort_stream) {
         GSX_HIP(c, hipEventRecord(c->ev_pre, c->stream));   // the next sort on the sort stream starts behind this one
         c->pre_wait = true;
     }
-    c->perm_cur ^= 1u;
+    c->perm_cur = target;
     c->sorted_valid = true;
     return GSX_OK;
 }

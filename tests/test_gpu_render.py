@@ -520,17 +520,18 @@ def test_render_into_caller_owned_target(gsx_fresh, pkg, oracle, synth):
         gsx.set_framebuffer_dev(buf.data_ptr() + slot * nbytes, nbytes)
         gsx.sort(cam, download=False)
         gsx.render(u, w, h, download=False)
-    gsx.set_framebuffer_dev(None)                             # completes the queued frame into its slot
+    gsx.set_framebuffer_dev(None)                             # (queued frames keep the target they were started on)
     gsx.sync()
     host = buf.cpu().numpy()
     for slot in (0, 1):
         assert np.array_equal(host[slot * nbytes:(slot + 1) * nbytes].reshape(h, w, 4), img)
     assert np.all(host[2 * nbytes:] == 7)
     # the library's stream is a usable torch stream: work queued on it is ordered behind the frame
-    ext = torch.cuda.ExternalStream(gsx.stream(), device=torch.device("cuda", 0))
     gsx.set_framebuffer_dev(buf.data_ptr(), nbytes)
     gsx.render(u, w, h, download=False)
     gsx.set_framebuffer_dev(None)
+    # (gsx_get_stream orders the main stream behind every frame queued so far: frames alternate between two streams)
+    ext = torch.cuda.ExternalStream(gsx.stream(), device=torch.device("cuda", 0))
     with torch.cuda.stream(ext):
         copy = buf[:nbytes].clone()
     ext.synchronize()
@@ -555,7 +556,8 @@ def test_render_into_caller_owned_target(gsx_fresh, pkg, oracle, synth):
 @pytest.mark.parametrize("lod", [False, True])
 def test_two_stream_pipeline_matches_single_stream(gsx_fresh, pkg, oracle, synth, lod):
     """The LOD cut and the depth sort of frame k+1 run on a second stream beside the binning / rasterizing of frame k
-    (option async_sort, default on).  Twelve frames of an orbit queued without a single read-back, each into its own slot of a
+    (option async_sort, default on), and two frames are in flight at a time on two more (option frames_in_flight, default 2).
+    Twelve frames of an orbit queued without a single read-back, each into its own slot of a
     caller-owned buffer, must be byte-identical to the same twelve frames with everything on one stream - also with
     profiling level 2 on, which moves every 4th sort to the main stream."""
     import importlib
@@ -584,6 +586,7 @@ def test_two_stream_pipeline_matches_single_stream(gsx_fresh, pkg, oracle, synth
 
     def run(async_on, level):
         gsx.set_option("async_sort", async_on)
+        gsx.set_option("frames_in_flight", 2 if async_on else 1)
         gsx.set_profiling(level)
         gsx.sync()
         assert hip.hipMemset(buf, 0, frames * nbytes) == 0
