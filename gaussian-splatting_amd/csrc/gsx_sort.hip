@@ -68,10 +68,13 @@ __global__ __launch_bounds__(GSX_SORT_NT) void k_keygen_hist0(const float4* __re
                                                               const uint32_t* __restrict__ m_ptr, float cx, float cy, float cz,
                                                               uint32_t key_lo, uint32_t key_span, uint32_t shift, uint32_t bits,
                                                               uint32_t wide_mask, uint32_t* __restrict__ keys, uint32_t* __restrict__ cnt, uint32_t max_cols,
-                                                              GsxDevFlags* __restrict__ flags) {
+                                                              GsxDevFlags* __restrict__ flags, uint32_t* __restrict__ m_copy) {
     __shared__ uint32_t s_hist[GSX_RADIX_MAX_DIGITS * GSX_HREP];
     const uint32_t nd = 1u << bits, mask = nd - 1u;
     const uint32_t m = *m_ptr;
+    // the frame drawn from this permutation reads the selection's size from a word of its own (the next selection may
+    // overwrite *m_ptr as soon as this sort is done)
+    if (m_copy && blockIdx.x == 0 && threadIdx.x == 0) *m_copy = m;
     const uint32_t n_cols = gsx_n_cols(m, GSX_SORT_TILE, max_cols);
     uint32_t top = 0;                                  // OR of the key bits above the ungated passes
     for (uint32_t col = gsx_logical_block(); col < n_cols; col += gridDim.x) {
@@ -225,6 +228,7 @@ struct GsxSortBuffers {
     uint64_t ws_words;
     uint32_t* result;
     bool with_events;      // profiling events / sampled scatter launches (the context's own sort only)
+    uint32_t* m_copy = nullptr;   // device word that receives the selection's size (the context's own sort only)
 };
 
 static int launch_sort_in(gsx_ctx* c, const GsxSortBuffers& sb, hipStream_t st) {
@@ -272,11 +276,11 @@ static int launch_sort_in(gsx_ctx* c, const GsxSortBuffers& sb, hipStream_t st) 
     if (c->sel_iota)
         hipLaunchKernelGGL(k_keygen_hist0<true>, dim3(g), dim3(GSX_SORT_NT), 0, st, c->pos4, nullptr, c->m_dev, c->cam[0],
                            c->cam[1], c->cam[2], key_lo, key_span, plan.shift[0], plan.bits[0], wide_mask, sb.keys[0], sb.ws, cols,
-                           c->flags);
+                           c->flags, sb.m_copy);
     else
         hipLaunchKernelGGL(k_keygen_hist0<false>, dim3(g), dim3(GSX_SORT_NT), 0, st, c->pos4, c->sel_idx, c->m_dev, c->cam[0],
                            c->cam[1], c->cam[2], key_lo, key_span, plan.shift[0], plan.bits[0], wide_mask, sb.keys[0], sb.ws, cols,
-                           c->flags);
+                           c->flags, sb.m_copy);
     if (profiling) GSX_HIP(c, hipEventRecord(c->ev[EV_KEY1], st));
     uint32_t cur = 0;
     uint32_t* result = sb.result;
@@ -322,6 +326,7 @@ int gsx_launch_sort(gsx_ctx* c) {
     const uint32_t target = (c->perm_cur + 1u) % GSX_PERM_RING;
     sb.result = c->perm[target];
     sb.with_events = true;
+    sb.m_copy = c->m_perm + target;
     // (with every stage bracketed by events - profiling level 1 - the stages run one after another on the main stream, and so
     // does a sort that carries a level-2 sample)
     const bool sampled = c->prof_level == 2 && c->prof_frame % GSX_SAMPLE_EVERY == 0u;
@@ -344,9 +349,6 @@ int gsx_launch_sort(gsx_ctx* c) {
     if (c->frame_done_rec[target]) GSX_HIP(c, hipStreamWaitEvent(st, c->ev_frame_done[target], 0));
     const int rc = launch_sort_in(c, sb, st);
     if (rc != GSX_OK) return rc;
-    // the frame drawn from this permutation reads the selection's size from a word of its own: the next selection may
-    // overwrite m_dev as soon as this sort is done
-    GSX_HIP(c, hipMemcpyAsync(c->m_perm + target, c->m_dev, sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
     GSX_HIP(c, hipEventRecord(c->ev_sorted, st));   // what a frame's stream waits for before it draws this permutation
     c->sorted_rec = true;
     if (async) {

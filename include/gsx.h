@@ -101,10 +101,11 @@ const char* gsx_last_error(const gsx_ctx* ctx);
 int gsx_sync(gsx_ctx* ctx);
 /* 0 = no events (default).  1 = HIP events around every stage and every radix scatter launch
  * (gsx_get_timings fills all *_ms fields; the ~20 events cost tens of microseconds per frame).
- * 2 = sampled: per frame only ONE thing is bracketed, rotating frame by frame: the k_radix_scatter launch of pass 0, 1, ...
- * of the depth sort (scatter_ms = the latest such launch, scatter_sample says which pass), then keys + sort as a whole.
- * The samples go through a ring of event pairs, so frames can be queued back to back without
- * reading anything in between; gsx_get_scatter_samples returns what has accumulated. */
+ * 2 = sampled: in every 4th sort ONE thing is bracketed, rotating: the k_radix_scatter launch of pass 0, 1, ... of the
+ * depth sort (scatter_ms = the latest such launch, scatter_sample says which pass), then keys + sort as a whole.  A sampled
+ * sort runs on the main stream instead of beside the previous frame (see gsx_sort), so the bracket times the kernel, not
+ * its share of a GPU it splits with the rasterizer.  The samples go through a ring of event pairs, so frames can be queued
+ * back to back without reading anything in between; gsx_get_scatter_samples returns what has accumulated. */
 int gsx_set_profiling(gsx_ctx* ctx, int enabled);
 int gsx_get_timings(gsx_ctx* ctx, gsx_timings* out);
 /* Profiling level 2 (no counterpart in the reference): per radix pass p < 4 of the depth sort, the summed
@@ -112,7 +113,7 @@ int gsx_get_timings(gsx_ctx* ctx, gsx_timings* out);
  * queued work like gsx_get_timings; reset != 0 clears the sums. */
 int gsx_get_scatter_samples(gsx_ctx* ctx, double sum_ms[4], uint32_t launches[4], int reset);
 /* Profiling level 2 also brackets keys + sort AS A WHOLE (from before the key kernel to behind the last radix pass) in
- * every (passes + 1)-th sort of the rotation: summed duration (ms) and number of such sorts since the last reset. */
+ * every (passes + 1)-th SAMPLED sort of the rotation: summed duration (ms) and number of such sorts since the last reset. */
 int gsx_get_sort_samples(gsx_ctx* ctx, double* sum_ms, uint32_t* sorts, int reset);
 /* Tuning knobs of the frame loop (no counterpart in the reference; 0 restores the default):
  *   "pair_budget"   (tile, splat) pairs one near -> far iteration may emit (sizes the pair buffers,
@@ -123,6 +124,10 @@ int gsx_get_sort_samples(gsx_ctx* ctx, double* sum_ms, uint32_t* sorts, int rese
  *                   last frame, the default takes everything behind that window in one iteration)
  *   "no_history"    1 = always pre-queue iterations for the whole selection (default: only as many ranks as
  *                   the last 8 frames needed before every tile was saturated, +25 %; the rest runs on demand)
+ *   "async_sort"    0 = queue LOD cuts and depth sorts on the main stream, behind the frame in flight (default 1: on a
+ *                   stream of their own, beside it; same results)
+ *   "frames_in_flight"  1 = wait for frame k before queuing frame k + 1 (default 2: frame k + 1 is binned and rasterized on a
+ *                   second frame slot while frame k is still running; same pixels)
  *   "lod_walk"      1 = cut an octree with the general kernels (every node tests itself, then walks its ancestor chain)
  *                   even when it is laid out in BFS order, for which the default is the top-down level-by-level cut;
  *                   same result, kept for A/B measurements and as the path for trees in any other order
@@ -162,8 +167,11 @@ int gsx_get_selection(gsx_ctx* ctx, uint32_t* idx_out_host, uint32_t capacity, u
  * (replaces the queue.writeBuffer(sortIndexBuffer) upload, SplatMesh.h:56-57).
  * idx_out_host (nullable) receives the m sorted indices.
  * With idx_out_host == NULL the call only queues the sort; it may be issued while
- * a frame queued by gsx_render is still running (the result goes to a second
- * permutation buffer, so that frame keeps drawing its own order). ---- */
+ * frames queued by gsx_render are still running: the result goes to another
+ * permutation buffer (there are three), so those frames keep drawing their own
+ * order, and the sort runs on a stream of its own BESIDE them (as does a
+ * camera-dependent LOD cut queued before it).  gsx_render / gsx_sync / any call
+ * that reads or replaces the selection is ordered behind it by events. ---- */
 int gsx_sort(gsx_ctx* ctx, const float cam_pos[3], uint32_t* idx_out_host);
 int gsx_get_sorted_dev(gsx_ctx* ctx, const uint32_t** idx_dev, uint32_t* m);
 /* gsx_sort for callers that cannot allocate device memory (code under HIP graph capture, tight serving loops, harnesses
@@ -192,23 +200,29 @@ int gsx_get_keys(gsx_ctx* ctx, const float cam_pos[3], float* dist_out_host, uin
  * With rgba8_out_host == NULL the call only QUEUES the frame (near -> far
  * iterations).  The frame is complete, and the device
  * framebuffer valid, after the next gsx_sync / gsx_get_timings / download;
- * that call also runs the on-demand iterations a heavy frame may still need. ---- */
+ * that call also runs the on-demand iterations a heavy frame may still need.
+ * Up to two queued frames are in flight at a time, on two streams (the call
+ * waits on the host only for the frame BEFORE the last one, whose slot it
+ * takes).  A frame is a pure function of (scene, permutation, uniforms):
+ * neither the iteration schedule nor what else runs beside it changes a byte. ---- */
 int gsx_render(gsx_ctx* ctx, const gsx_uniforms* u, uint32_t width, uint32_t height,
                uint32_t y0, uint32_t y1, void* rgba8_out_host);
-/* Device pointer of the RGBA8 frame (valid until the next gsx_render with another size or gsx_destroy;
- * contents complete after gsx_sync, see gsx_render). */
+/* Device pointer of the RGBA8 frame queued LAST (contents complete after gsx_sync, see gsx_render).  The library keeps one
+ * framebuffer per frame slot, so consecutive frames land in alternating buffers: ask again after every gsx_render. */
 int gsx_get_framebuffer_dev(gsx_ctx* ctx, const void** rgba8_dev, uint32_t* width, uint32_t* height);
 /* Render target in caller-owned device memory (the counterpart of the swap-chain texture view the reference's
- * render pass is given, renderer.cpp:132-176 / main.cpp:243-252).  Completes the queued frame into the current
- * target first (including its on-demand iterations), then directs every following gsx_render to rgba8_dev, which
+ * render pass is given, renderer.cpp:132-176 / main.cpp:243-252).  Directs every FOLLOWING gsx_render to rgba8_dev, which
  * must hold width*height*4 bytes of each frame rendered into it (capacity_bytes is checked per frame ->
- * GSX_E_INVALID).  NULL returns to the library's own framebuffer.  The caller keeps the memory alive until the
+ * GSX_E_INVALID); frames already queued keep the target they were started on, on-demand iterations included, and the
+ * call does not wait for them.  NULL returns to the library's own framebuffers.  The caller keeps the memory alive until the
  * target is changed again or the context is destroyed; rows outside a rendered band are left untouched.
  * Used by the multi-GPU view batches: each rank renders straight into its slot of the batch that RCCL gathers. */
 int gsx_set_framebuffer_dev(gsx_ctx* ctx, void* rgba8_dev, uint64_t capacity_bytes);
-/* The HIP stream (hipStream_t) every call on this context is queued on, for callers that order their own device
- * work or collectives against the frames (e.g. torch.cuda.ExternalStream + RCCL).  No reference counterpart:
- * the reference's queue is the wgpu::Queue handed to SplatMesh::initialize (SplatMesh.h:72). */
+/* The context's main HIP stream (hipStream_t), for callers that order their own device work or collectives against the
+ * frames (e.g. torch.cuda.ExternalStream + RCCL).  The library queues sorts and every other frame on streams of its own;
+ * this call makes the main stream wait (on the device) for every sort and frame queued SO FAR, so work the caller queues
+ * on the returned stream afterwards runs behind them: call it again whenever new frames have been queued.  No reference
+ * counterpart: the reference's queue is the wgpu::Queue handed to SplatMesh::initialize (SplatMesh.h:72). */
 int gsx_get_stream(gsx_ctx* ctx, void** hip_stream);
 
 /* ---- multi-GPU: the gather of finished pixels to one rank.  No counterpart in the reference,
@@ -227,9 +241,9 @@ int gsx_comm_destroy(gsx_comm* comm);
 /* Every rank contributes send_bytes bytes at send_dev; on `root`, rank r's bytes land at recv_dev + recv_offsets[r]
  * (recv_bytes[r] of them; recv_bytes[r] must equal what rank r sends, recv_bytes[root] the root's own send_bytes).
  * recv_* are read on the root only.  With offsets = y0 * width * 4 the bands of one frame are gathered straight into
- * place; with offsets = r * frame_bytes * batch a batch of whole frames per rank.  Queued on the context's stream:
- * ordered behind the frames already queued (a frame queued by gsx_render is completed first, which may wait for it on
- * the host), complete after gsx_sync (or any stream wait) on the root. */
+ * place; with offsets = r * frame_bytes * batch a batch of whole frames per rank.  Queued on the context's main stream
+ * behind the frames already queued (they are completed first, which waits for them on the host), complete after
+ * gsx_sync (or any wait on gsx_get_stream's stream) on the root. */
 int gsx_gather(gsx_ctx* ctx, gsx_comm* comm, const void* send_dev, uint64_t send_bytes, void* recv_dev,
                const uint64_t* recv_offsets, const uint64_t* recv_bytes, int root);
 
