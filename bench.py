@@ -126,22 +126,28 @@ def cpu_baseline_parallel(splats, views, n_frames, threads):
 
 
 def kernel_rooflines_from_profile(n_splats):
-    """HBM rates of the key / count / cull+projection kernels from the committed rocprofv3 --kernel-trace --stats summary of
-    this command (profiles/r2_bench_kernel_stats.csv).  Not measured in this run: the file is cited with every figure."""
-    path = os.path.join(ROOT, "profiles", "r2_bench_kernel_stats.csv")
+    """HBM rates of the key / count / cull+projection / LOD kernels from the committed rocprofv3 --kernel-trace --stats summaries
+    (tools/final_profile.sh runs this command once more with everything on ONE stream, so that the durations are the kernels'
+    own; tools/lod_profile.sh profiles cfg 3).  Not measured in this run: every figure cites its file."""
+    path = os.path.join(ROOT, "profiles", "r2_bench_serialized_kernel_stats.csv")
     if not os.path.exists(path):
         return None
     bytes_per_call = {   # algorithmic bytes per launch at n_splats splats (DESIGN.md section 4)
         "k_keygen_hist0": KEYGEN_BYTES_PER_SPLAT * n_splats,
         "k_radix_hist<unsigned int": COUNT_BYTES_PER_SPLAT * n_splats,
     }
-    out = {"source": "profiles/r2_bench_kernel_stats.csv (rocprofv3 --kernel-trace --stats of `python bench.py --cpu-frames 0`; not measured in this run)"}
+    out = {"source": "profiles/r2_bench_serialized_kernel_stats.csv (rocprofv3 --kernel-trace --stats of `python bench.py --cpu-frames 0 "
+                     "--opt async_sort=0 --opt frames_in_flight=1`; not measured in this run)"}
     for r in csv.DictReader(open(path)):
         for key, b in bytes_per_call.items():
             if key in r["Name"]:
                 avg_us = float(r["AverageNs"]) / 1e3
                 out[key.split("<")[0]] = {"avg_us": avg_us, "calls": int(r["Calls"]), "algorithmic_bytes": b,
                                           "hbm_gbs": b / (avg_us * 1e-6) / 1e9, "hbm_frac": b / (avg_us * 1e-6) / 1e9 / HBM_PEAK_GBS}
+    for name, fn in (("k_chunk_count", "r2_chunk_count_roofline.json"), ("lod_cut_cfg3", "r2_cfg3_lod_roofline.json")):
+        p = os.path.join(ROOT, "profiles", fn)
+        if os.path.exists(p):
+            out[name] = dict(json.load(open(p)), source="profiles/" + fn)
     return out
 
 
@@ -225,13 +231,21 @@ def main():
     if dist is not None and a.gather != "none":
         gather_kind = a.gather
         if a.gather == "gsx":
+            # every rank takes the same path through the collectives below whatever fails locally: rank 0 broadcasts the id
+            # together with a "have one" byte, and nobody enters the (collective) communicator set-up without it
+            idt = torch.zeros(129, dtype=torch.uint8, device=dev)
+            if rank == 0 and world > 1:
+                try:
+                    idt[:128].copy_(torch.from_numpy(g.comm_unique_id()))
+                    idt[128] = 1
+                except Exception as e:      # noqa: BLE001 — librccl missing or unusable: fall back below
+                    gather_note = f"gsx_comm_unique_id failed: {e}"
+            if world > 1:
+                dist.broadcast(idt, 0)
             try:
-                idt = torch.zeros(128, dtype=torch.uint8, device=dev)
-                if rank == 0 and world > 1:
-                    idt.copy_(torch.from_numpy(g.comm_unique_id()))
-                if world > 1:
-                    dist.broadcast(idt, 0)
-                g.comm_init(idt.cpu().numpy() if world > 1 else None, rank, world)
+                if world > 1 and int(idt[128].item()) != 1:
+                    raise RuntimeError("no RCCL id from rank 0")
+                g.comm_init(idt[:128].cpu().numpy() if world > 1 else None, rank, world)
                 probe = torch.full((4096,), rank + 1, dtype=torch.uint8, device=dev)
                 sink = torch.zeros(4096 * world, dtype=torch.uint8, device=dev) if rank == 0 else None
                 torch.cuda.synchronize()

@@ -11,3 +11,11 @@ python tools/ktrace.py gpurun_out/prof_r2f 48 0.5 > gpurun_out/r2_bench_kernel_t
 cat gpurun_out/r2_bench_kernel_stats.txt
 python -c "
 import json; d=json.load(open('gpurun_out/r2_bench.json')); print(d['ms_per_step'], d['value'], d['roofline']['frac'], d['cpu_baseline'])"
+# the same command with everything on one stream, one frame at a time: per-kernel durations that are the kernels' own
+rm -rf gpurun_out/prof_r2s
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_r2s -o r2s -- python3 bench.py --cpu-frames 0 --opt async_sort=0 --opt frames_in_flight=1 > gpurun_out/r2_bench_serialized_under_rocprof.json 2> gpurun_out/r2_bench_serialized_under_rocprof.err
+python tools/kstats.py gpurun_out/prof_r2s > gpurun_out/r2_bench_serialized_kernel_stats.txt
+cp gpurun_out/prof_r2s/*/*kernel_stats.csv gpurun_out/r2_bench_serialized_kernel_stats.csv 2>/dev/null || cp gpurun_out/prof_r2s/*kernel_stats.csv gpurun_out/r2_bench_serialized_kernel_stats.csv
+python tools/chunk_count_roofline.py gpurun_out/prof_r2s > gpurun_out/r2_chunk_count_roofline.json
+python tools/ktrace.py gpurun_out/prof_r2s 48 0.2 > gpurun_out/r2_bench_serialized_kernel_trace_excerpt.txt
+cat gpurun_out/r2_bench_serialized_kernel_stats.txt gpurun_out/r2_chunk_count_roofline.json
