@@ -487,11 +487,12 @@ def main():
             out["stage_ms"] = stage
             out["stage_ms_note"] = f"{n_prof} extra frames after the timed region with every stage bracketed by HIP events (adds ~65 us per frame)"
             shades, blends = acc["raster_shades"] / n_prof, acc["raster_blends"] / n_prof
+            staged = acc.get("raster_staged", 0.0) / n_prof
             r_ms = stage["raster_ms"]
             if r_ms > 0:
                 out["roofline_raster"] = {
                     "kernel": "k_raster (tile rasterizer, all iterations of a frame)", "bound": "valu (packed f32) + lds",
-                    "raster_ms": r_ms, "wave_splat_shades": shades, "pixel_blends": blends,
+                    "raster_ms": r_ms, "pairs_binned": int(pairs), "pairs_staged": staged, "wave_splat_shades": shades, "pixel_blends": blends,
                     "blends_per_s": blends / (r_ms * 1e-3),
                     "lane_hit_rate": blends / (shades * 128.0) if shades else None,
                     "valu_tflops": blends * BLEND_FLOP / (r_ms * 1e-3) / 1e12,

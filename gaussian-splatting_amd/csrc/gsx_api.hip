@@ -285,7 +285,8 @@ int gsx_get_timings(gsx_ctx* c, gsx_timings* out) {
             std::vector<unsigned long long> st(GSX_STAT_BYTES / 8);
             GSX_HIP(c, hipMemcpy(st.data(), c->stat, GSX_STAT_BYTES, hipMemcpyDeviceToHost));
             t.raster_shades = 0; t.raster_blends = 0;
-            for (int sh = 0; sh < 64; ++sh) { t.raster_shades += st[sh * 16]; t.raster_blends += st[sh * 16 + 1]; }
+            t.raster_staged = 0;
+            for (int sh = 0; sh < 64; ++sh) { t.raster_shades += st[sh * 16]; t.raster_blends += st[sh * 16 + 1]; t.raster_staged += st[sh * 16 + 2]; }
         }
     }
     t.scatter_sample = 0;

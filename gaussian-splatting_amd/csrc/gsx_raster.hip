@@ -528,7 +528,7 @@ __global__ __launch_bounds__(GSX_RASTER_NT) void k_raster(const uint16_t* __rest
                                                           uint32_t* __restrict__ aux, uint8_t* __restrict__ fb,
                                                           unsigned long long* __restrict__ stat) {
     constexpr uint32_t NW = GSX_RASTER_NT / 64;                   // 2 waves = 2 halves
-    unsigned long long n_shades = 0, n_blends = 0;                // COUNT: (wave, splat) visits / pixels blended
+    unsigned long long n_shades = 0, n_blends = 0, n_staged = 0;  // COUNT: (wave, splat) visits / pixels blended / pairs staged (wave 0)
     static_assert(GSX_RASTER_BATCH == GSX_RASTER_NT, "one staged splat per thread");
     __shared__ float4 s_a[GSX_RASTER_BATCH];  // cx cy ex ey
     __shared__ float4 s_m[GSX_RASTER_BATCH];  // m00 m01 m10 m11
@@ -575,6 +575,7 @@ __global__ __launch_bounds__(GSX_RASTER_NT) void k_raster(const uint16_t* __rest
     for (uint32_t lo = begin; lo < end;) {
         const uint32_t nb = min(static_cast<uint32_t>(GSX_RASTER_BATCH), end - lo);
         lo_done = lo + nb;
+        if (COUNT && wave == 0) n_staged += nb;
         __syncthreads();  // previous batch fully consumed
         if (tid == 0) s_live[0] = 0;
         // stage: thread j gathers splat j of the batch and tests its quad against the two 16x8 halves
@@ -682,6 +683,7 @@ __global__ __launch_bounds__(GSX_RASTER_NT) void k_raster(const uint16_t* __rest
         unsigned long long* shard = stat + (tile & 63u) * 16u;
         atomicAdd(shard, n_shades);
         atomicAdd(shard + 1, n_blends);
+        if (wave == 0) atomicAdd(shard + 2, n_staged);
     }
     // retire the tile or park its accumulators for the next iteration
     __syncthreads();

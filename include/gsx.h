@@ -92,6 +92,7 @@ typedef struct gsx_timings {
     uint32_t scatter_sample; /* profiling level 2: 1 + index of the radix pass whose scatter launch scatter_ms times; else 0 */
     uint64_t raster_shades;  /* profiling level 1: (wave, splat) visits of the rasterizer's shading loop in the last frame */
     uint64_t raster_blends;  /* profiling level 1: pixels blended (a visit blends up to 128 pixels) */
+    uint64_t raster_staged;  /* profiling level 1: (tile, splat) pairs the rasterizer staged before their tile was saturated (of tile_pairs binned) */
 } gsx_timings;
 
 /* ---- lifecycle (replaces Renderer::init device bring-up, renderer.cpp:3-100) ---- */
