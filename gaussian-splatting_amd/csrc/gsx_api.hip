@@ -161,6 +161,7 @@ int gsx_destroy(gsx_ctx* c) {
         dev_free(&sl->pair_ws); dev_free(&sl->scan_block_sums); dev_free(&sl->fb);
         dev_free(&sl->sub_off); dev_free(&sl->rank_box); dev_free(&sl->rank_rec); dev_free(&sl->ctl); dev_free(&sl->live_bits);
         dev_free(&sl->tile_state); dev_free(&sl->accum);
+        dev_free(&sl->tile_depth[0]); dev_free(&sl->tile_depth[1]); dev_free(&sl->tile_band); dev_free(&sl->band_masks);
         if (sl->ctl_host) { (void)hipHostFree(sl->ctl_host); sl->ctl_host = nullptr; }
         if (sl->frame_ev) { (void)hipEventDestroy(sl->frame_ev); sl->frame_ev = nullptr; }
     }
@@ -203,6 +204,8 @@ int gsx_set_option(gsx_ctx* c, const char* name, uint64_t value) {
         c->opt_no_history = value ? 1 : 0;
     } else if (!std::strcmp(name, "lod_walk")) {
         c->opt_lod_walk = value ? 1 : 0;
+    } else if (!std::strcmp(name, "tile_caps")) {
+        c->opt_tile_caps = value > 2 ? 1 : value;      // (2: caps at 1/8 of the predicted depth - exercises the redo path in tests)
     } else if (!std::strcmp(name, "async_sort")) {
         c->opt_async_sort = value ? 1 : 0;
     } else if (!std::strcmp(name, "frames_in_flight")) {
@@ -316,6 +319,8 @@ static int upload_common(gsx_ctx* c, const void* aos_dev, uint64_t n) {
     if ((rc = gsx_frame_finish(c))) return rc;
     c->main_dirty = true;
     for (bool& r : c->frame_done_rec) r = false;
+    c->hist_valid = false;
+    c->parked.hist_valid = false;
     c->sorted_rec = false;
     if ((rc = alloc_scene(c, n))) return rc;
     c->n = n;

@@ -39,6 +39,10 @@
 #define GSX_LIVE_ROW_WORDS 8         // 256 tiles per row as bits
 #define GSX_TBOX_NONE 0x000000FFu    // packed tile box with tx0 > tx1: splat culled
 #define GSX_MAX_SCHED 8              // scheduled near -> far iterations per frame
+// Per-tile rank caps (gsx_raster.hip): ranks from the near end are cut into bands [R_j, R_{j+1}), R_j a multiple of 1024:
+// 0, 1, 2 ... 8 K ranks in steps of 1 K, then four bands per octave.  Band GSX_BANDS - 1 is open ended.
+#define GSX_BANDS 64
+#define GSX_BAND_INF GSX_BANDS       // cap band of a tile without a cap
 #define GSX_CTL_CURSORS (GSX_MAX_SCHED + 1)
 
 // Device-resident control block of the frame loop (gsx_raster.hip).
@@ -67,6 +71,9 @@ struct GsxFrameState {
     uint32_t need_base = 0;   // ranks the schedule was derived from (before the margin)
     const uint32_t* sorted = nullptr;   // the permutation this frame draws (one of gsx_ctx::perm)
     bool continuing = false;
+    bool caps_on = false;     // the frame bins every tile only up to its predicted saturation depth (band masks)
+    bool redo = false;        // continuation that supplies what the caps withheld from tiles that did not saturate
+    uint32_t redos = 0;
 };
 
 // Error/diagnostic words written by kernels (never zeroed implicitly).
@@ -132,6 +139,18 @@ struct GsxFrameSlot {
     float4* accum = nullptr;           // per tile x 256 pixels: (r, g, b, transmittance)
     uint64_t accum_cap = 0;
     GsxFrameState frame;
+    // per-tile history: the rank (from the near end) at which each tile retired in the slot's last frame (0 = it did not),
+    // written by k_raster into tile_depth[depth_cur]; the next frame of the slot reads it as a prediction
+    uint32_t* tile_depth[2] = {nullptr, nullptr};
+    uint64_t tile_depth_cap[2] = {0, 0};
+    uint32_t depth_cur = 0;
+    uint8_t* tile_band = nullptr;      // cap band per tile of the frame in flight (GSX_BAND_INF = none)
+    uint64_t tile_band_cap = 0;
+    uint32_t* band_masks = nullptr;    // GSX_BANDS x tiles_y x GSX_LIVE_ROW_WORDS: bit = the tile still wants ranks of that band
+    uint64_t band_masks_cap = 0;
+    bool hist_valid = false;           // tile_depth[depth_cur] describes a finished frame with the geometry below
+    uint32_t hist_w = 0, hist_h = 0, hist_y0 = 0, hist_y1 = 0;
+    float hist_wt[16] = {}, hist_proj[16] = {};
     hipEvent_t frame_ev = nullptr;
     bool frame_pending = false;
 };
@@ -228,7 +247,7 @@ struct gsx_ctx : GsxFrameSlot {
     bool rest_merged = false;          // the last schedule took everything behind the first window in one iteration
     float density0 = 0.0f;             // (tile, splat) pairs per rank in the last frame's first window (0 = unknown)
     // tuning (gsx_set_option); 0 = automatic
-    uint64_t opt_pair_budget = 0, opt_chunk_first = 0, opt_chunk_growth = 0, opt_no_history = 0, opt_lod_walk = 0;
+    uint64_t opt_pair_budget = 0, opt_chunk_first = 0, opt_chunk_growth = 0, opt_no_history = 0, opt_lod_walk = 0, opt_tile_caps = 1;
     // The depth sort of frame k+1 runs on a stream of its own, beside the binning / rasterizing of frame k (it writes the
     // OTHER permutation buffer and its own key / value arrays).  Ordering is by events:
     //   sort stream waits for   ev_pre         (main stream, recorded when a selection / upload was queued since the last sort)

@@ -93,6 +93,8 @@ typedef struct gsx_timings {
     uint64_t raster_shades;  /* profiling level 1: (wave, splat) visits of the rasterizer's shading loop in the last frame */
     uint64_t raster_blends;  /* profiling level 1: pixels blended (a visit blends up to 128 pixels) */
     uint64_t raster_staged;  /* profiling level 1: (tile, splat) pairs the rasterizer staged before their tile was saturated (of tile_pairs binned) */
+    uint32_t render_capped;  /* 1 if the last frame binned every tile only up to its predicted saturation depth (option "tile_caps") */
+    uint32_t render_redos;   /* continuations that supplied pairs a cap had withheld from a tile that did not saturate (0 as a rule) */
 } gsx_timings;
 
 /* ---- lifecycle (replaces Renderer::init device bring-up, renderer.cpp:3-100) ---- */
@@ -129,6 +131,9 @@ int gsx_get_sort_samples(gsx_ctx* ctx, double* sum_ms, uint32_t* sorts, int rese
  *                   stream of their own, beside it; same results)
  *   "frames_in_flight"  1 = wait for frame k before queuing frame k + 1 (default 2: frame k + 1 is binned and rasterized on a
  *                   second frame slot while frame k is still running; same pixels)
+ *   "tile_caps"     0 = bin every live tile through the whole window (default 1: a tile is binned only up to 1.5 x the depth
+ *                   at which it saturated in the frame slot's last frame, when the picture has moved by at most a few tiles
+ *                   since; a tile that does not saturate after all gets the withheld pairs in a continuation; same pixels)
  *   "lod_walk"      1 = cut an octree with the general kernels (every node tests itself, then walks its ancestor chain)
  *                   even when it is laid out in BFS order, for which the default is the top-down level-by-level cut;
  *                   same result, kept for A/B measurements and as the path for trees in any other order

@@ -269,7 +269,8 @@ def test_dense_scene_default_schedule_matches_oracle(gsx_fresh, pkg, oracle, syn
     img2 = gsx.render(pkg.make_uniforms(proj2, view2), w, h)
     pairs_default = gsx.timings()["tile_pairs"]
     check_image(img2, oracle.render(splats, perm2, orc.make_uniforms(proj2, view2), w, h))
-    # tiles did retire: binning everything in one shot emits more pairs, and the same bytes
+    # tiles did retire: binning everything in one shot (and without per-tile rank caps) emits more pairs, and the same bytes
+    gsx.set_option("tile_caps", 0)
     gsx.set_option("chunk_first", 1 << 30)
     one = gsx.render(pkg.make_uniforms(proj2, view2), w, h)
     assert gsx.timings()["tile_pairs"] > pairs_default
@@ -611,3 +612,57 @@ def test_two_stream_pipeline_matches_single_stream(gsx_fresh, pkg, oracle, synth
     if tree is not None:
         gsx.select_all()
         tree.close()
+
+
+def test_tile_rank_caps_same_pixels_fewer_pairs_and_redo(gsx_fresh, pkg, oracle, synth):
+    """Per-tile rank caps (option tile_caps, default on): with a steady view every tile is binned only up to 1.5 x the depth at
+    which it saturated in the frame slot's last frame.  Same bytes as without caps, far fewer pairs; and when the prediction
+    is wrong - here the scene grows eightfold between two frames of the same view, so tiles have to look much deeper than
+    their caps - the withheld pairs are supplied by a redo continuation and the bytes are still the same."""
+    gsx = gsx_fresh
+    w, h, n = 960, 540, 1_500_000
+    splats = oracle.raw_to_splat(synth.clustered_cloud(n, seed=6))
+    view, proj, cam = camera(oracle, w, h)
+    u = pkg.make_uniforms(proj, view)
+    gsx.upload(splats)
+    perm = gsx.sort(cam)
+    gsx.set_option("tile_caps", 0)
+    ref = gsx.render(u, w, h).copy()
+    pairs_plain = gsx.timings()["tile_pairs"]
+    assert gsx.timings()["render_capped"] == 0
+    gsx.set_option("tile_caps", 1)
+    capped = 0
+    for k in range(6):                                       # both frame slots need a finished frame of this view first
+        gsx.sort(cam, download=False)
+        img = gsx.render(u, w, h)
+        t = gsx.timings()
+        assert np.array_equal(img, ref), k
+        if t["render_capped"]:
+            capped += 1
+            assert t["render_redos"] == 0
+            assert t["tile_pairs"] < 0.9 * pairs_plain, (t["tile_pairs"], pairs_plain)
+    assert capped >= 3
+    # a prediction that is wrong: tile_caps = 2 caps every tile at 1/8 of the depth it needed last frame, so nearly every tile
+    # that saturated before is starved now and gets the withheld pairs from a redo continuation
+    gsx.set_option("tile_caps", 2)
+    for k in range(3):
+        gsx.sort(cam, download=False)
+        img = gsx.render(u, w, h)
+        t = gsx.timings()
+        assert t["render_capped"] == 1 and t["render_redos"] == 1, (t["render_capped"], t["render_redos"])
+        assert np.array_equal(img, ref), k
+    gsx.set_option("tile_caps", 1)
+    # ... and one that is wrong because the scene changed under a steady view: frames of every 8th splat, then all of them
+    gsx.select_list(np.arange(0, n, 8, dtype=np.uint32))
+    for k in range(4):
+        gsx.sort(cam, download=False)
+        sparse = gsx.render(u, w, h)
+    gsx.select_all()
+    gsx.sort(cam, download=False)
+    assert np.array_equal(gsx.render(u, w, h), ref)
+    assert not np.array_equal(sparse, ref)
+    # a view that moved by more than a few tiles switches the caps off by itself
+    view2, proj2, cam2 = camera(oracle, w, h, steps=3)
+    gsx.sort(cam2, download=False)
+    gsx.render(pkg.make_uniforms(proj2, view2), w, h)
+    assert gsx.timings()["render_capped"] == 0
