@@ -206,6 +206,9 @@ int gsx_set_option(gsx_ctx* c, const char* name, uint64_t value) {
         c->opt_lod_walk = value ? 1 : 0;
     } else if (!std::strcmp(name, "tile_caps")) {
         c->opt_tile_caps = value > 2 ? 1 : value;      // (2: caps at 1/8 of the predicted depth - exercises the redo path in tests)
+    } else if (!std::strcmp(name, "tile_caps_radius")) {
+        if (value > 32) { c->err = "tile_caps_radius above 32"; return GSX_E_INVALID; }
+        c->opt_caps_radius = value;
     } else if (!std::strcmp(name, "async_sort")) {
         c->opt_async_sort = value ? 1 : 0;
     } else if (!std::strcmp(name, "frames_in_flight")) {

@@ -160,7 +160,7 @@ struct gsx_ctx : GsxFrameSlot {
     hipStream_t stream = nullptr;
     std::string err;
     bool profiling = false;            // level 1: events around every stage
-    int prof_level = 0;                // 0 off, 1 all stages, 2 sampled (one scatter launch per frame)
+    int prof_level = 0;                // 0 off, 1 all stages, 2 sampled (one scatter launch, or keys + sort as a whole, in every 4th sort)
     uint32_t prof_frame = 0;           // sorts launched (rotates the sampled pass)
     int sampled_pass = -1;             // level 2: pass whose scatter launch carries events in the last sort
     // level 2 samples: a ring of event pairs, so frames can be queued back to back and the durations collected later
@@ -237,6 +237,7 @@ struct gsx_ctx : GsxFrameSlot {
     uint8_t* fb_ext = nullptr;         // caller-owned render target of the frames launched from now on (gsx_set_framebuffer_dev), nullptr = the slot's own
     uint64_t fb_ext_cap = 0;
     uint64_t pair_grown = 0;           // budget a frame had to grow to (kept for later frames)
+    uint32_t caps_off_frames = 0, caps_backoff = 0;   // rank caps: frames left without them after a failed prediction / length of the next such pause
     unsigned long long* stat = nullptr;   // GSX_STAT_BYTES of sharded counters: [shard*16 + 0] (wave, splat) shades, [+1] pixels blended
     // ranks (from the near end) earlier frames needed before every tile was retired; ~0u = the whole selection
     uint32_t need_hist[8] = {};
@@ -247,7 +248,7 @@ struct gsx_ctx : GsxFrameSlot {
     bool rest_merged = false;          // the last schedule took everything behind the first window in one iteration
     float density0 = 0.0f;             // (tile, splat) pairs per rank in the last frame's first window (0 = unknown)
     // tuning (gsx_set_option); 0 = automatic
-    uint64_t opt_pair_budget = 0, opt_chunk_first = 0, opt_chunk_growth = 0, opt_no_history = 0, opt_lod_walk = 0, opt_tile_caps = 1;
+    uint64_t opt_pair_budget = 0, opt_chunk_first = 0, opt_chunk_growth = 0, opt_no_history = 0, opt_lod_walk = 0, opt_tile_caps = 1, opt_caps_radius = 0;
     // The depth sort of frame k+1 runs on a stream of its own, beside the binning / rasterizing of frame k (it writes the
     // OTHER permutation buffer and its own key / value arrays).  Ordering is by events:
     //   sort stream waits for   ev_pre         (main stream, recorded when a selection / upload was queued since the last sort)

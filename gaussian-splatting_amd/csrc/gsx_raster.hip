@@ -985,10 +985,13 @@ int gsx_launch_render(gsx_ctx* c, const gsx_uniforms* u, uint32_t w, uint32_t h,
     {
         const bool same = c->hist_valid && c->hist_w == w && c->hist_h == h && c->hist_y0 == y0 && c->hist_y1 == y1 &&
                           c->tile_depth[c->depth_cur] && c->tile_depth_cap[c->depth_cur] >= n_tiles;
-        if (same && c->opt_tile_caps && !c->opt_no_history && c->opt_chunk_first % 1024u == 0u && c->aabb_valid) {   // (cursors must stay multiples of 1024)
-            // how far the scene's bounding box moves on screen between the two frames (pixels, worst corner in front of both
-            // cameras); with a corner behind a camera (the camera stands inside the box) nearby splats move by more than any
-            // corner, so only an unchanged view counts as steady then
+        if (c->caps_off_frames) --c->caps_off_frames;                      // (a redo continuation switched the caps off for a while)
+        else if (same && c->opt_tile_caps && !c->opt_no_history && c->opt_chunk_first % 1024u == 0u && c->aabb_valid) {   // (cursors must stay multiples of 1024)
+            // how far the scene moves on screen between the two frames: the worst corner (in pixels) of the INNER half of the
+            // scene's bounding box - the box itself is stretched by outliers, and a camera inside it is the rule for them.
+            // With a corner behind a camera (the camera stands inside the inner box) nearby splats move by more than any corner,
+            // so only an unchanged view counts as steady then.  The estimate may be too small for splats close to the camera:
+            // a prediction that fails costs a redo continuation and switches the caps off for a growing number of frames.
             float moved = 0.0f, dmat = 0.0f;
             bool ok = true, behind = false;
             for (int k = 0; k < 16; ++k) {
@@ -996,8 +999,11 @@ int gsx_launch_render(gsx_ctx* c, const gsx_uniforms* u, uint32_t w, uint32_t h,
                 dmat = fmaxf(dmat, fabsf(vp.proj[k] - c->hist_proj[k]));
             }
             for (int k = 0; k < 8 && ok; ++k) {
-                const float p[3] = {(k & 1) ? c->aabb_max[0] : c->aabb_min[0], (k & 2) ? c->aabb_max[1] : c->aabb_min[1],
-                                    (k & 4) ? c->aabb_max[2] : c->aabb_min[2]};
+                float p[3];
+                for (int ax = 0; ax < 3; ++ax) {
+                    const float mid = 0.5f * (c->aabb_min[ax] + c->aabb_max[ax]), half = 0.25f * (c->aabb_max[ax] - c->aabb_min[ax]);
+                    p[ax] = ((k >> ax) & 1) ? mid + half : mid - half;
+                }
                 float scr[2][2];
                 bool front = true;
                 for (int which = 0; which < 2; ++which) {
@@ -1019,7 +1025,7 @@ int gsx_launch_render(gsx_ctx* c, const gsx_uniforms* u, uint32_t w, uint32_t h,
             if (behind && !(dmat <= 1.0e-6f)) ok = false;
             if (ok) {
                 const int radius = 1 + static_cast<int>(ceilf(1.5f * moved / static_cast<float>(GSX_TILE_W)));
-                if (radius <= 4) cap_radius = radius;
+                if (radius <= static_cast<int>(c->opt_caps_radius ? c->opt_caps_radius : 4u)) cap_radius = radius;
             }
         }
     }
@@ -1193,6 +1199,8 @@ int gsx_frame_finish_active(gsx_ctx* c) {
                     f.redo = true;
                     f.continuing = true;
                     ++f.redos;
+                    c->caps_backoff = c->caps_backoff ? (c->caps_backoff < 64u ? c->caps_backoff * 2u : 64u) : 4u;
+                    c->caps_off_frames = c->caps_backoff;
                     int rc;
                     GSX_HIP(c, hipMemcpyAsync(&c->ctl->cursor[0], &start, 4, hipMemcpyHostToDevice, c->fstream));
                     GSX_HIP(c, hipMemcpyAsync(&c->ctl->stall, &zero, 4, hipMemcpyHostToDevice, c->fstream));
@@ -1241,6 +1249,7 @@ int gsx_frame_finish_active(gsx_ctx* c) {
     }
     c->tim.tile_pairs = c->ctl_host->total_pairs;
     c->tim.render_iters = c->ctl_host->iters_used;
+    if (f.caps_on && !f.redos && c->caps_backoff) --c->caps_backoff;      // predictions that hold earn the trust back
     c->tim.render_capped = f.caps_on ? 1u : 0u;
     c->tim.render_redos = f.redos;
     {   // what the slot's next frame may predict from: this frame's per-tile depths, valid for this geometry and view

@@ -645,16 +645,23 @@ def test_tile_rank_caps_same_pixels_fewer_pairs_and_redo(gsx_fresh, pkg, oracle,
     # a prediction that is wrong: tile_caps = 2 caps every tile at 1/8 of the depth it needed last frame, so nearly every tile
     # that saturated before is starved now and gets the withheld pairs from a redo continuation
     gsx.set_option("tile_caps", 2)
-    for k in range(3):
+    gsx.sort(cam, download=False)
+    img = gsx.render(u, w, h)
+    t = gsx.timings()
+    assert t["render_capped"] == 1 and t["render_redos"] == 1, (t["render_capped"], t["render_redos"])
+    assert np.array_equal(img, ref)
+    for k in range(4):                                       # a failed prediction pauses the caps (4 frames the first time)
         gsx.sort(cam, download=False)
         img = gsx.render(u, w, h)
-        t = gsx.timings()
-        assert t["render_capped"] == 1 and t["render_redos"] == 1, (t["render_capped"], t["render_redos"])
-        assert np.array_equal(img, ref), k
+        assert gsx.timings()["render_capped"] == 0 and np.array_equal(img, ref), k
+    gsx.sort(cam, download=False)
+    img = gsx.render(u, w, h)                                # ... then they are tried again (and fail again: still 1/8)
+    t = gsx.timings()
+    assert t["render_capped"] == 1 and t["render_redos"] == 1 and np.array_equal(img, ref)
     gsx.set_option("tile_caps", 1)
     # ... and one that is wrong because the scene changed under a steady view: frames of every 8th splat, then all of them
     gsx.select_list(np.arange(0, n, 8, dtype=np.uint32))
-    for k in range(4):
+    for k in range(12):                                      # (long enough for the pause above to run out)
         gsx.sort(cam, download=False)
         sparse = gsx.render(u, w, h)
     gsx.select_all()
