@@ -673,3 +673,78 @@ def test_tile_rank_caps_same_pixels_fewer_pairs_and_redo(gsx_fresh, pkg, oracle,
     gsx.sort(cam2, download=False)
     gsx.render(pkg.make_uniforms(proj2, view2), w, h)
     assert gsx.timings()["render_capped"] == 0
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_random_call_sequences_match_the_strict_order(pkg, oracle, synth, seed):
+    """Two contexts get the same random sequence of calls - selections (all / list / octree cut), sorts and frames with and
+    without read-back, tile bands, render targets, option changes, syncs.  One runs with everything the library overlaps or
+    predicts switched on (sort stream, two frames in flight, rank caps, history), the other strictly in order with all of it
+    off.  Every permutation and every frame read back must agree byte for byte: orderings between the streams that the
+    dedicated tests do not think of show up here."""
+    import importlib
+    lodm = importlib.import_module("gaussian_splatting_amd.lod")
+    rng = np.random.default_rng(seed)
+    w, h = 320, 208
+    tree = lodm.build_octree(synth.clustered_cloud(120_000, seed=seed))
+    n = tree.n
+    fast, strict = pkg.Gsx(0), pkg.Gsx(0)
+    try:
+        for g in (fast, strict):
+            tree.upload(g)
+        for k, v in (("async_sort", 0), ("frames_in_flight", 1), ("tile_caps", 0), ("no_history", 1)):
+            strict.set_option(k, v)
+        poses = []
+        for f in range(6):
+            world, _ = oracle.orbit_world(4.0, (0.0, 1.0, 0.0), 0.004, f)          # a slow orbit: the rank caps stay in play
+            view, proj, vp, cam = oracle.camera(world, 45.0, w / h)
+            poses.append((pkg.make_uniforms(proj, view), cam, vp))
+        sorted_once = False
+        frames = perms = 0
+        for step in range(400):
+            op = rng.choice(["sort"] * 6 + ["render"] * 9 + ["band"] * 2 + ["sel_all", "sel_list", "sel_oct", "sync", "prof", "timings"])
+            u, cam, vp = poses[int(rng.integers(0, len(poses)))] if rng.random() < 0.3 else poses[step // 100]
+            if op == "sort":
+                if rng.random() < 0.3:
+                    a, b = fast.sort(cam), strict.sort(cam)
+                    assert np.array_equal(a, b), step
+                    perms += 1
+                else:
+                    fast.sort(cam, download=False); strict.sort(cam, download=False)
+                sorted_once = True
+            elif op == "render" and sorted_once:
+                if rng.random() < 0.4:
+                    a, b = fast.render(u, w, h), strict.render(u, w, h)
+                    assert np.array_equal(a, b), step
+                    frames += 1
+                else:
+                    fast.render(u, w, h, download=False); strict.render(u, w, h, download=False)
+            elif op == "band" and sorted_once:
+                y0 = int(rng.integers(0, h - 16)); y1 = int(rng.integers(y0 + 1, h + 1))
+                a, b = fast.render(u, w, h, y0, y1), strict.render(u, w, h, y0, y1)
+                assert np.array_equal(a[y0:y1], b[y0:y1]), step
+            elif op == "sel_all":
+                fast.select_all(); strict.select_all(); sorted_once = False
+            elif op == "sel_list":
+                idx = rng.choice(n, size=int(rng.integers(1, n)), replace=False).astype(np.uint32)
+                fast.select_list(idx); strict.select_list(idx); sorted_once = False
+            elif op == "sel_oct":
+                thr = float(rng.choice([0.002, 0.0005, 0.02]))
+                want = rng.random() < 0.5
+                a, b = fast.select_octree(vp, thr, want_count=want), strict.select_octree(vp, thr, want_count=want)
+                if want:
+                    assert a == b, step
+                sorted_once = False
+            elif op == "sync":
+                fast.sync(); strict.sync()
+            elif op == "prof":
+                fast.set_profiling(int(rng.choice([0, 0, 2, 1])))
+            elif op == "timings" and sorted_once:
+                fast.timings(); strict.timings()
+        # a final frame of every pose, read back
+        for u, cam, vp in poses:
+            assert np.array_equal(fast.sort(cam), strict.sort(cam))
+            assert np.array_equal(fast.render(u, w, h), strict.render(u, w, h))
+        assert frames >= 10 and perms >= 5, (frames, perms)
+    finally:
+        fast.close(); strict.close(); tree.close()
