@@ -13,7 +13,8 @@ N > 1, two shardings over a replicated splat set:
   --shard views (default; weak scaling): a step is a batch of N views, one per rank.  Every rank renders the pose of
       the N = 1 run so that the per-GPU work is fixed (--distinct-views: rank r renders pose r of the pose set).  The
       frames are rendered straight into the slots of a batch buffer and each full batch of 8 frames goes to rank 0 in
-      ONE gsx_gather (grouped RCCL send / recv on the library's stream) inside the timed region.
+      ONE gsx_gather (grouped RCCL send / recv on the library's exchange stream, beside the frames of the next batch)
+      inside the timed region.
   --shard bands (strong scaling, BASELINE.json configs[4]): ONE 3840x2160 frame of the overlap-stress scene per step;
       rank r sorts the (replicated) scene and renders tile band r, the bands are gathered in place into rank 0's
       frame, and after the timed region rank 0 checks that frame byte for byte against the frame it renders alone.
@@ -199,7 +200,21 @@ def main():
         os.environ.setdefault("WORLD_SIZE", "1")
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        # The control collectives of this script (id broadcast, self-check vote, barrier, max of the elapsed times) are host
+        # values and go through gloo; device tensors (the torch.distributed fallback gather) go through nccl = RCCL, whose
+        # communicator torch creates on first use only.  The pixels themselves are exchanged by gsx_gather on the library's
+        # own RCCL communicator.  (A torch NCCL communicator that exists beside the library's streams costs every frame
+        # ~0.03 ms on one GPU - measured with GSX_BENCH_PG=nccl - whether or not it is ever used.)
+        pg = os.environ.get("GSX_BENCH_PG", "mixed")
+        if pg == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            try:
+                dist.init_process_group(backend="cpu:gloo,cuda:nccl")
+            except Exception as e:      # noqa: BLE001 — no gloo on this host: everything through nccl, as before
+                _dbg(f"gloo + nccl process group failed ({e}); nccl only")
+                pg = "nccl"
+                dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback)"
     dev = torch.device("cuda", local_rank)
     _dbg(f"process group ready: rank {rank}/{world}")
@@ -226,14 +241,15 @@ def main():
     bands = mg.shard_bands(H, max(world, 1))
     y0, y1 = bands[rank] if bands_mode else (0, H)
 
-    # ---- the exchange: gsx_gather (RCCL point-to-point on the library's stream), checked once before it is trusted ----
+    # ---- the exchange: gsx_gather (RCCL point-to-point on the library's exchange stream), checked once before it is trusted ----
     gather_kind, gather_note = "none", None
     if dist is not None and a.gather != "none":
         gather_kind = a.gather
         if a.gather == "gsx":
             # every rank takes the same path through the collectives below whatever fails locally: rank 0 broadcasts the id
             # together with a "have one" byte, and nobody enters the (collective) communicator set-up without it
-            idt = torch.zeros(129, dtype=torch.uint8, device=dev)
+            ctl_dev = dev if pg == "nccl" else torch.device("cpu")
+            idt = torch.zeros(129, dtype=torch.uint8, device=ctl_dev)
             if rank == 0 and world > 1:
                 try:
                     idt[:128].copy_(torch.from_numpy(g.comm_unique_id()))
@@ -258,11 +274,16 @@ def main():
                     ok = int(all(np.all(got[r] == r + 1) for r in range(world)))
             except Exception as e:      # noqa: BLE001 — any failure here means: do not use this path
                 ok, gather_note = 0, f"gsx_gather unavailable on rank {rank}: {e}"
-            flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+            flag = torch.tensor([ok], dtype=torch.int32, device=ctl_dev)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             if int(flag.item()) != 1:
                 gather_kind = "torch"
                 gather_note = gather_note or "gsx_gather self-check failed on some rank; fell back to torch.distributed.gather"
+    # the torch.distributed fallback moves device tensors: a nccl (= RCCL) group of its own, created only when it is used
+    # (the decision above is the same on every rank)
+    torch_group = None
+    if dist is not None and gather_kind == "torch" and pg != "nccl":
+        torch_group = dist.new_group(backend="nccl", device_id=dev)
     _dbg(f"gather: {gather_kind}")
 
     keep = []
@@ -278,10 +299,13 @@ def main():
         fg = mg.GsxFrameGather(g, rank, world, fb_bytes, a.gather_batch, alloc)
     elif not bands_mode and gather_kind == "torch":
         ext = torch.cuda.ExternalStream(g.stream(), device=dev)
-        bg = mg.BatchedFrameGather(dist, rank, world, fb_bytes, a.gather_batch, dev, stream=ext)
+        bg = mg.BatchedFrameGather(dist, rank, world, fb_bytes, a.gather_batch, dev, stream=ext, group=torch_group)
     band_recv = [torch.zeros(fb_bytes, dtype=torch.uint8, device=dev) for _ in range(world)] if (bands_mode and gather_kind == "torch" and rank == 0) else None
     frame_no = 0
     exchange = True     # switched off after the timed region: what follows is rank 0's alone
+    band_pending = []   # bands mode: framebuffers of the frames whose exchange has not been posted yet
+    band_fbs = [alloc(fb_bytes)[0] for _ in range(4)] if (bands_mode and gather_kind == "gsx") else []
+    band_last = [None]  # framebuffer the last exchange of the timed region gathered into
 
     def step(pose=None, uniforms=None):
         nonlocal frame_no
@@ -289,18 +313,25 @@ def main():
         uni = u_mine if uniforms is None else uniforms
         g.sort(pos, download=False)          # queued behind the running frame
         if bands_mode:
+            if exchange and gather_kind == "gsx":
+                # Frames go round a ring of 4 framebuffers and the exchange of frame k is posted two frames late, just before
+                # frame k+2 is queued: gsx_gather completes the frame it ships, and that is the one wait for frame k the
+                # library's two-frames-in-flight pipeline has at this point anyway; frame k+2 renders into other memory, so it
+                # does not wait for the exchange either.
+                if len(band_pending) == 2:
+                    mg.gather_bands_gsx(g, band_pending.pop(0), bands, W, rank)
+                g.set_framebuffer_dev(band_fbs[frame_no % len(band_fbs)], fb_bytes)
             if y1 > y0:
                 g.render(uni, W, H, y0, y1, download=False)
             if not exchange:
                 pass
             elif gather_kind == "gsx":
-                fb_ptr = g.framebuffer_dev()[0]
-                mg.gather_bands_gsx(g, fb_ptr, bands, W, rank)
+                band_pending.append(band_fbs[frame_no % len(band_fbs)])
             elif gather_kind == "torch":
                 g.sync()
                 fb_ptr = g.framebuffer_dev()[0]
                 t = torch.as_tensor(DevArray(fb_ptr, fb_bytes), device=dev)
-                mg.gather_to_rank0(dist, t, rank, world, band_recv)
+                mg.gather_to_rank0(dist, t, rank, world, band_recv, group=torch_group)
         else:
             batcher = fg or bg
             if batcher is not None:
@@ -319,6 +350,11 @@ def main():
     def drain():
         """Complete the last frame and send what is left of the current batch."""
         batcher = fg or bg
+        while band_pending:
+            band_last[0] = band_pending.pop(0)
+            mg.gather_bands_gsx(g, band_last[0], bands, W, rank)
+        if bands_mode:
+            g.set_framebuffer_dev(None)
         if batcher is not None and frame_no:
             g.set_framebuffer_dev(None)
             if bg is not None:
@@ -327,8 +363,11 @@ def main():
             batcher.finish()
 
     def fence():
+        """Everything this rank has queued is complete, then a barrier (an all-reduce of a host word over gloo), then once more."""
+        g.sync()
+        torch.cuda.synchronize()
         if dist is not None:
-            dist.barrier()
+            dist.all_reduce(torch.zeros(1, dtype=torch.int32, device=dev if pg == "nccl" else "cpu"))
         g.sync()
         torch.cuda.synchronize()
 
@@ -337,24 +376,34 @@ def main():
         step()
     fence()
     _dbg("warm-up done")
+    # a full collection of Python's cyclic garbage collector walks every object torch and numpy have created (tens of
+    # milliseconds, seen as ONE stalled step some hundred steps in): collect now and park what exists in the permanent generation
+    import gc
+    gc.collect()
+    gc.freeze()
     g.scatter_samples(reset=True)
     g.sort_samples(reset=True)
     # Frames are queued back to back (the next frame's sort is queued behind the running frame; gsx_render waits for the
     # previous frame only to check whether it needs more iterations).  Nothing is read back inside the loop: the sampled
     # launches sit in the library's event ring and are collected after the closing fence.
+    stamps = [] if os.environ.get("GSX_BENCH_STEPTIMES") else None    # (diagnostic: host time after every step's calls)
     t0 = time.perf_counter()
     for i in range(a.steps):
         step()
+        if stamps is not None:
+            stamps.append(time.perf_counter() - t0)
     drain()
     fence()
     elapsed = time.perf_counter() - t0
     _dbg("timed region closed")
+    if stamps is not None and rank == 0:
+        np.save(os.environ["GSX_BENCH_STEPTIMES"], np.asarray(stamps))
     per_pass, pass_n = g.scatter_samples(reset=True)     # mean launch duration of each radix pass over the timed region
     sort_ms_timed, sort_n_timed = g.sort_samples(reset=True)
     t = g.timings()
     pairs, iters, passes = t["tile_pairs"], t["render_iters"], t["sort_passes"]
     if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if pg == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
@@ -369,7 +418,7 @@ def main():
         if gather_kind == "torch":
             gathered = mg.compose_bands(band_recv, bands, W).cpu().numpy()
         else:
-            hip.hipMemcpy(C.c_void_p(gathered.ctypes.data), C.c_void_p(g.framebuffer_dev()[0]), C.c_size_t(fb_bytes), C.c_int(2))
+            hip.hipMemcpy(C.c_void_p(gathered.ctypes.data), C.c_void_p(band_last[0] or g.framebuffer_dev()[0]), C.c_size_t(fb_bytes), C.c_int(2))
         g.sort(my_view[2], download=False)
         alone = g.render(u_mine, W, H).reshape(-1)
         bands_match = bool(np.array_equal(gathered, alone)) if (world == 1 or gather_kind != "none") else None
@@ -450,7 +499,7 @@ def main():
                        "splats": n, "width": W, "height": H, "views_per_step_per_gpu": None if bands_mode else 1,
                        "poses": "one pose" if bands_mode else ("rank r renders pose r" if a.distinct_views else "every rank renders the N=1 pose (fixed per-GPU work)"),
                        "sharding": ("screen-space tile bands over replicated splats" if bands_mode else "camera views over replicated splats"),
-                       "gather": {"gsx": f"gsx_gather (grouped RCCL send/recv on the library's stream)" + ("" if bands_mode else f", batches of {a.gather_batch} frames"),
+                       "gather": {"gsx": f"gsx_gather (grouped RCCL send/recv on the library's exchange stream)" + ("" if bands_mode else f", batches of {a.gather_batch} frames"),
                                   "torch": "torch.distributed.gather (nccl = RCCL)", "none": "none"}[gather_kind]},
             "fps": frames_total / elapsed,
             "tile_pairs": int(pairs),
@@ -471,6 +520,9 @@ def main():
             out["fps_1080p"] = out["fps"]
         if gather_note:
             out["config"]["gather_note"] = gather_note
+        if dist is not None:
+            out["config"]["control_collectives"] = ("torch.distributed over nccl" if pg == "nccl" else
+                                                    "torch.distributed over gloo (host words: id broadcast, barrier, max of the elapsed times); pixels over RCCL")
         if bands_match is not None:
             out["bands_match_single_gpu_frame"] = bands_match
         if sort_n_timed:

@@ -144,6 +144,7 @@ int gsx_destroy(gsx_ctx* c) {
     (void)hipSetDevice(c->device);
     c->frame_pending = false;
     c->parked.frame_pending = false;
+    if (c->comm_stream) (void)hipStreamSynchronize(c->comm_stream);
     if (c->sort_stream) (void)hipStreamSynchronize(c->sort_stream);
     if (c->parked.fstream) (void)hipStreamSynchronize(c->parked.fstream);
     if (c->fstream) (void)hipStreamSynchronize(c->fstream);
@@ -175,6 +176,10 @@ int gsx_destroy(gsx_ctx* c) {
         if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     for (hipEvent_t e : {c->ev_sorted, c->ev_pre, c->ev_frame_done[0], c->ev_frame_done[1], c->ev_frame_done[2]})
         if (e) (void)hipEventDestroy(e);
+    for (auto& g : c->gathers)
+        if (g.ev) (void)hipEventDestroy(g.ev);
+    if (c->ev_comm_pre) (void)hipEventDestroy(c->ev_comm_pre);
+    if (c->comm_stream) (void)hipStreamDestroy(c->comm_stream);
     if (c->sort_stream) (void)hipStreamDestroy(c->sort_stream);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -728,8 +733,10 @@ int gsx_get_stream(gsx_ctx* c, void** hip_stream) {
     // frames may be in flight on the library's other streams: what the caller queues on the main stream from now on runs
     // behind every frame and sort queued so far
     gsx_join_sort(c);
+    if ((rc = gsx_comm_join(c))) return rc;
     for (GsxFrameSlot* sl : {static_cast<GsxFrameSlot*>(c), &c->parked})
         if (sl->frame_pending && sl->fstream != c->stream) GSX_HIP(c, hipStreamWaitEvent(c->stream, sl->frame_ev, 0));
+    c->stream_handed_out = true;
     *hip_stream = static_cast<void*>(c->stream);
     return GSX_OK;
 }

@@ -4,8 +4,9 @@
 // The reference has no counterpart (single process, single GPU).  MI355X peers are fully
 // connected by xGMI, so a gather is best done as DIRECT sends: inside one ncclGroupStart / ncclGroupEnd the
 // root posts one ncclRecv per peer and every peer one ncclSend; each transfer uses its own link and there is
-// no ring.  Everything is queued on the context's HIP stream, i.e. ordered behind the frames already queued on
-// it, and nothing here waits on the host.
+// no ring.  The exchange is queued on a stream of its own (gsx_ctx::comm_stream), ordered behind the frames that
+// render into the memory it ships and beside every other frame: the next batch is rendered while RCCL moves this one.
+// A later frame that targets memory an exchange still uses waits for it on the device (gsx_comm_guard).
 //
 // librccl is loaded with dlopen when the first communicator call is made: single-GPU users of libgsx do not
 // load it at all, and a missing RCCL is an error of these calls only.
@@ -76,6 +77,28 @@ struct gsx_comm {
         }                                                                                 \
     } while (0)
 
+// st waits for the exchanges that still read or write [lo, hi): a frame about to render there, as a rule.
+int gsx_comm_guard(gsx_ctx* c, hipStream_t st, const uint8_t* lo, const uint8_t* hi) {
+    for (auto& g : c->gathers) {
+        if (!g.pending) continue;
+        if (hipEventQuery(g.ev) == hipSuccess) { g.pending = false; continue; }
+        bool hit = false;
+        for (int k = 0; k < 2; ++k) hit = hit || (g.lo[k] && g.lo[k] < hi && lo < g.hi[k]);
+        if (hit) GSX_HIP(c, hipStreamWaitEvent(st, g.ev, 0));
+    }
+    return GSX_OK;
+}
+
+// The main stream waits for every exchange queued so far: whoever synchronizes with it next, or queues behind it, sees them done.
+int gsx_comm_join(gsx_ctx* c) {
+    for (auto& g : c->gathers) {
+        if (!g.pending) continue;
+        if (hipEventQuery(g.ev) == hipSuccess) { g.pending = false; continue; }
+        GSX_HIP(c, hipStreamWaitEvent(c->stream, g.ev, 0));
+    }
+    return GSX_OK;
+}
+
 extern "C" {
 
 int gsx_comm_unique_id(void* id128_out) {
@@ -113,6 +136,7 @@ int gsx_comm_destroy(gsx_comm* m) {
     if (!m) return GSX_E_INVALID;
     if (m->comm) {
         (void)hipSetDevice(m->ctx->device);
+        if (m->ctx->comm_stream) (void)hipStreamSynchronize(m->ctx->comm_stream);
         (void)hipStreamSynchronize(m->ctx->stream);
         (void)rccl()->CommDestroy(m->comm);
     }
@@ -127,26 +151,61 @@ int gsx_gather(gsx_ctx* c, gsx_comm* m, const void* send_dev, uint64_t send_byte
     if (is_root && (!recv_dev || !recv_offsets || !recv_bytes)) return GSX_E_INVALID;
     if (is_root && recv_bytes[root] != send_bytes) { c->err = "gsx_gather: recv_bytes[root] differs from the root's own send_bytes"; return GSX_E_INVALID; }
     GSX_HIP(c, hipSetDevice(c->device));
-    // a frame queued by gsx_render may still need on-demand iterations: they must be queued before the
-    // exchange that ships its pixels (no-op when the frame was completed already, e.g. by gsx_set_framebuffer_dev)
-    { const int frc = gsx_frame_finish(c); if (frc) return frc; }
+    // the memory this exchange reads (what is sent) and writes (root: everything received)
+    const uint8_t* lo[2] = {static_cast<const uint8_t*>(send_dev), nullptr};
+    const uint8_t* hi[2] = {lo[0] + send_bytes, nullptr};
+    if (is_root) {
+        uint64_t a = ~0ull, b = 0;
+        for (int r = 0; r < m->nranks; ++r) {
+            if (!recv_bytes[r]) continue;
+            a = recv_offsets[r] < a ? recv_offsets[r] : a;
+            b = recv_offsets[r] + recv_bytes[r] > b ? recv_offsets[r] + recv_bytes[r] : b;
+        }
+        if (b > a) { lo[1] = static_cast<const uint8_t*>(recv_dev) + a; hi[1] = static_cast<const uint8_t*>(recv_dev) + b; }
+    }
+    // A frame queued by gsx_render may still need on-demand iterations, which only the host can queue: the
+    // frames that render into this memory are completed first.  Frames queued into OTHER memory stay in flight - a caller
+    // that posts the exchange of a batch one or two frames late (multigpu.py) never makes the host wait here.
+    for (int k = 0; k < 2; ++k) { const int frc = gsx_frame_finish_touching(c, lo[k], hi[k]); if (frc) return frc; }
+    if (!c->comm_stream) {
+        GSX_HIP(c, hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
+        GSX_HIP(c, hipEventCreateWithFlags(&c->ev_comm_pre, hipEventDisableTiming));
+        for (auto& g : c->gathers) GSX_HIP(c, hipEventCreateWithFlags(&g.ev, hipEventDisableTiming));
+    }
+    hipStream_t st = c->comm_stream;
+    // The frames that wrote this memory are complete: the host has just waited for them.  A caller that was handed the main
+    // stream (gsx_get_stream) may have filled the send buffer there with work of its own, so the exchange is ordered behind
+    // what that stream holds now - only then: the wait would also chain the exchange to a frame of the NEXT batch that is in
+    // flight on the main stream, and through the guard of the frame after it the two frame slots to each other.
+    if (c->stream_handed_out) {
+        GSX_HIP(c, hipEventRecord(c->ev_comm_pre, c->stream));
+        GSX_HIP(c, hipStreamWaitEvent(st, c->ev_comm_pre, 0));
+        c->stream_handed_out = false;
+    }
+    gsx_ctx::GatherRec& rec = c->gathers[c->gather_pos++ % GSX_GATHER_RING];
+    if (rec.pending) GSX_HIP(c, hipEventSynchronize(rec.ev));    // (more than GSX_GATHER_RING exchanges in flight: the oldest is waited for)
+    rec.pending = false;
     if (is_root && send_bytes) {   // the root's own part never touches the network
         unsigned char* dst = static_cast<unsigned char*>(recv_dev) + recv_offsets[root];
-        if (dst != send_dev) GSX_HIP(c, hipMemcpyAsync(dst, send_dev, send_bytes, hipMemcpyDeviceToDevice, c->stream));
+        if (dst != send_dev) GSX_HIP(c, hipMemcpyAsync(dst, send_dev, send_bytes, hipMemcpyDeviceToDevice, st));
     }
-    if (m->nranks == 1) return GSX_OK;
-    RcclApi* api = rccl();
-    if (is_root) {
-        GSX_RCCL(c, api, api->GroupStart());
-        for (int r = 0; r < m->nranks; ++r) {
-            if (r == root || recv_bytes[r] == 0) continue;
-            const ncclResult_t rr = api->Recv(static_cast<unsigned char*>(recv_dev) + recv_offsets[r], recv_bytes[r], ncclUint8, r, m->comm, c->stream);
-            if (rr != ncclSuccess) { (void)api->GroupEnd(); c->err = std::string("ncclRecv: ") + api->GetErrorString(rr); return GSX_E_HIP; }
+    if (m->nranks > 1) {
+        RcclApi* api = rccl();
+        if (is_root) {
+            GSX_RCCL(c, api, api->GroupStart());
+            for (int r = 0; r < m->nranks; ++r) {
+                if (r == root || recv_bytes[r] == 0) continue;
+                const ncclResult_t rr = api->Recv(static_cast<unsigned char*>(recv_dev) + recv_offsets[r], recv_bytes[r], ncclUint8, r, m->comm, st);
+                if (rr != ncclSuccess) { (void)api->GroupEnd(); c->err = std::string("ncclRecv: ") + api->GetErrorString(rr); return GSX_E_HIP; }
+            }
+            GSX_RCCL(c, api, api->GroupEnd());
+        } else if (send_bytes) {
+            GSX_RCCL(c, api, api->Send(send_dev, send_bytes, ncclUint8, root, m->comm, st));
         }
-        GSX_RCCL(c, api, api->GroupEnd());
-    } else if (send_bytes) {
-        GSX_RCCL(c, api, api->Send(send_dev, send_bytes, ncclUint8, root, m->comm, c->stream));
     }
+    for (int k = 0; k < 2; ++k) { rec.lo[k] = lo[k]; rec.hi[k] = hi[k]; }
+    GSX_HIP(c, hipEventRecord(rec.ev, st));
+    rec.pending = true;
     return GSX_OK;
 }
 

@@ -13,6 +13,7 @@
 #define GSX_PERM_RING 3           // permutation buffers: two frames in flight read two of them while the next sort fills the third
 #define GSX_SAMPLE_WHOLE 4
 #define GSX_SAMPLE_EVERY 4u       // profiling level 2 samples every 4th sort
+#define GSX_GATHER_RING 4          // exchanges whose memory ranges are remembered (an older one still running is waited for on the host)
 #define GSX_LOD_MAX_LEVELS 48
 #define GSX_LOD_TOP_NODES 4096u      // nodes of the leading octree levels one workgroup walks in LDS     // sample slot of "keys + sort as a whole" (slots 0..3: the scatter launch of a radix pass)
 #define GSX_STAT_BYTES (64 * 16 * 8)   // rasterizer counters (profiling level 1): 64 shards x one 128-byte line of u64 words
@@ -265,6 +266,19 @@ struct gsx_ctx : GsxFrameSlot {
     bool sort_join_pending = false;      // a sort was queued on sort_stream and the main stream has not waited for it yet
     bool main_dirty = true;              // the main stream holds work the next sort must see (selection, upload): record ev_pre
     bool pre_wait = false;               // ev_pre is recorded and the sort stream has not waited for it yet
+    // The exchange (gsx_gather) runs on a stream of its own, beside the frames queued after it.  Every exchange leaves a record
+    // of the memory it reads and writes; a frame that is about to render into such memory makes its stream wait for the record's
+    // event (gsx_comm_guard), and everything that joins the context's streams (gsx_sync, gsx_get_stream ...) joins this one too.
+    hipStream_t comm_stream = nullptr;   // created by the first gsx_gather
+    hipEvent_t ev_comm_pre = nullptr;
+    bool stream_handed_out = false;      // gsx_get_stream was called since the last exchange: the caller may have queued work of its own there
+    struct GatherRec {
+        const uint8_t* lo[2] = {nullptr, nullptr};    // [0] what is sent, [1] (root) what is received into
+        const uint8_t* hi[2] = {nullptr, nullptr};
+        hipEvent_t ev = nullptr;
+        bool pending = false;            // recorded and not yet known to have completed
+    } gathers[GSX_GATHER_RING];
+    uint32_t gather_pos = 0;
 
     // timing
     hipEvent_t ev[40] = {};
@@ -326,4 +340,7 @@ void gsx_sample_drain(gsx_ctx* c, uint32_t slot);   // folds a finished level-2 
 void gsx_join_sort(gsx_ctx* c);                  // main stream waits for the sort stream's latest sort (no host wait)
 int gsx_frame_finish(gsx_ctx* c);                // waits for every queued frame (oldest first); runs extra iterations if ranks are left
 int gsx_frame_finish_active(gsx_ctx* c);         // the same for the active slot's frame only
+int gsx_frame_finish_touching(gsx_ctx* c, const uint8_t* lo, const uint8_t* hi);   // only the queued frames that render into [lo, hi)
+int gsx_comm_guard(gsx_ctx* c, hipStream_t st, const uint8_t* lo, const uint8_t* hi);   // st waits for the exchanges that still use [lo, hi)
+int gsx_comm_join(gsx_ctx* c);                   // main stream waits for every exchange queued so far (no host wait)
 void gsx_slot_switch(gsx_ctx* c);                // the other frame slot becomes the active one

@@ -970,8 +970,11 @@ int gsx_launch_render(gsx_ctx* c, const gsx_uniforms* u, uint32_t w, uint32_t h,
         }
         c->fb_cur = c->fb_ext;
         c->fb_w = w; c->fb_h = h;
+        // an exchange that still ships (or fills) this memory runs on the exchange stream: the frame waits for it on the device
+        if ((rc = gsx_comm_guard(c, c->fstream, c->fb_cur, c->fb_cur + static_cast<uint64_t>(w) * h * 4)) != GSX_OK) return rc;
     } else {
         if ((rc = ensure(c, &c->fb, &c->fb_cap, static_cast<uint64_t>(w) * h * 4)) != GSX_OK) return rc;
+        if ((rc = gsx_comm_guard(c, c->fstream, c->fb, c->fb + static_cast<uint64_t>(w) * h * 4)) != GSX_OK) return rc;
         if (c->fb_w != w || c->fb_h != h || c->fb_cur != c->fb) {
             GSX_HIP(c, hipMemsetAsync(c->fb, 0, static_cast<uint64_t>(w) * h * 4, c->fstream));
             c->fb_w = w; c->fb_h = h;
@@ -1158,7 +1161,8 @@ void gsx_slot_switch(gsx_ctx* c) {
 // Every queued frame, oldest first; the active slot is the same afterwards as before.
 int gsx_frame_finish(gsx_ctx* c) {
     gsx_join_sort(c);      // whatever the caller queues next may read the permutation or rewrite the sort's inputs
-    int rc = GSX_OK;
+    int rc = gsx_comm_join(c);   // ... or the pixels an exchange is still moving
+    if (rc) return rc;
     if (c->parked.frame_pending && (!c->frame_pending || c->parked.frame_seq < c->frame_seq)) {
         gsx_slot_switch(c);
         rc = gsx_frame_finish_active(c);
@@ -1167,6 +1171,34 @@ int gsx_frame_finish(gsx_ctx* c) {
     }
     if ((rc = gsx_frame_finish_active(c))) return rc;
     if (c->parked.frame_pending) {
+        gsx_slot_switch(c);
+        rc = gsx_frame_finish_active(c);
+        gsx_slot_switch(c);
+    }
+    return rc;
+}
+
+// Only the queued frames that render into [lo, hi), oldest first; the others stay in flight.
+int gsx_frame_finish_touching(gsx_ctx* c, const uint8_t* lo, const uint8_t* hi) {
+    if (!lo || hi <= lo) return GSX_OK;
+    auto touches = [&](const GsxFrameSlot& s) {
+        if (!s.frame_pending || !s.fb_cur) return false;
+        const uint8_t* a = s.fb_cur;
+        const uint8_t* b = a + static_cast<uint64_t>(s.fb_w) * s.fb_h * 4;
+        return a < hi && lo < b;
+    };
+    const bool act = touches(*c);
+    bool par = touches(c->parked);
+    int rc = GSX_OK;
+    if (par && (!act || c->parked.frame_seq < c->frame_seq)) {
+        gsx_slot_switch(c);
+        rc = gsx_frame_finish_active(c);
+        gsx_slot_switch(c);
+        if (rc) return rc;
+        par = false;
+    }
+    if (act && (rc = gsx_frame_finish_active(c))) return rc;
+    if (par) {
         gsx_slot_switch(c);
         rc = gsx_frame_finish_active(c);
         gsx_slot_switch(c);

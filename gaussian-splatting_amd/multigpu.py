@@ -4,7 +4,7 @@ Two natural shardings, no data-path collective until the frames are finished (SU
   * camera views   : rank r renders views r, r + R, r + 2R, ...
   * tile-row bands : rank r renders rows [y0, y1) of one frame, band edges on tile rows
 The single exchange is the gather of RGBA8 pixels to rank 0.  On GPUs it goes through the library's own entry point
-(gsx_gather: grouped RCCL send / recv on the context's stream, GsxFrameGather / gather_bands_gsx below); the
+(gsx_gather: grouped RCCL send / recv on the context's exchange stream, GsxFrameGather / gather_bands_gsx below); the
 torch.distributed forms (gather_to_rank0, BatchedFrameGather) are the harness for the gloo CPU tests and the fallback.
 """
 TILE_H = 16
@@ -28,15 +28,15 @@ def shard_bands(height, world, tile_h=TILE_H):
     return bands
 
 
-def gather_to_rank0(dist, tensor, rank, world, bufs=None):
+def gather_to_rank0(dist, tensor, rank, world, bufs=None, group=None):
     """Gather equal-sized uint8 tensors to rank 0.  Returns the list on rank 0, None elsewhere."""
     import torch
     if rank == 0:
         if bufs is None:
             bufs = [torch.empty_like(tensor) for _ in range(world)]
-        dist.gather(tensor, bufs, dst=0)
+        dist.gather(tensor, bufs, dst=0, group=group)
         return bufs
-    dist.gather(tensor, None, dst=0)
+    dist.gather(tensor, None, dst=0, group=group)
     return None
 
 
@@ -64,9 +64,9 @@ class BatchedFrameGather:
     Per frame i (0, 1, 2 ... of this rank):  t = slot(i) -> render into t -> frame_done(i) once frame i has been
     queued completely.  finish() sends the last, possibly partial, batch and waits for everything."""
 
-    def __init__(self, dist, rank, world, frame_bytes, batch_frames, device, stream=None):
+    def __init__(self, dist, rank, world, frame_bytes, batch_frames, device, stream=None, group=None):
         import torch
-        self.dist, self.rank, self.world = dist, rank, world
+        self.dist, self.rank, self.world, self.group = dist, rank, world, group
         self.frame_bytes, self.batch_frames, self.stream = frame_bytes, batch_frames, stream
         self.batches = [torch.zeros(batch_frames * frame_bytes, dtype=torch.uint8, device=device) for _ in range(2)]
         self.recv = [[torch.zeros_like(b) for _ in range(world)] if rank == 0 else None for b in self.batches]
@@ -87,7 +87,7 @@ class BatchedFrameGather:
 
     def _start(self, b):
         with self._ctx():
-            self.work[b] = self.dist.gather(self.batches[b], self.recv[b], dst=0, async_op=True)
+            self.work[b] = self.dist.gather(self.batches[b], self.recv[b], dst=0, async_op=True, group=self.group)
         self.sent[b] = False
         self.gathers += 1
 
@@ -128,7 +128,8 @@ def band_gather_plan(bands, width):
 def gather_bands_gsx(g, fb_ptr, bands, width, rank, root=0):
     """Tile-band sharding, the exchange step: every rank has rendered rows [y0, y1) of the frame into ITS OWN full-size
     framebuffer at fb_ptr (device pointer); the bands are gathered into the root's framebuffer in place (the root's own
-    band is already there).  Queued on the context's stream."""
+    band is already there).  Runs on the context's exchange stream, behind the frame that rendered into fb_ptr and beside
+    the frames queued after it; call it one frame late (after the NEXT frame has been queued) and the host never waits."""
     off, size = band_gather_plan(bands, width)
     g.gather(fb_ptr + off[rank], size[rank], fb_ptr if rank == root else None, off if rank == root else None,
              size if rank == root else None, root)
@@ -136,14 +137,21 @@ def gather_bands_gsx(g, fb_ptr, bands, width, rank, root=0):
 
 class GsxFrameGather:
     """BatchedFrameGather on gsx_gather: every rank renders into the slots of a batch buffer, a full batch goes to rank 0
-    in one grouped RCCL exchange.  Everything (frames and gathers) is queued on the context's stream, so no host-side
-    or cross-stream waits exist: a batch buffer is re-used by frames queued BEHIND the gather that reads it.  Two batch
-    buffers alternate so that on rank 0 the batch received last stays readable while the next one is filled."""
+    in one grouped RCCL exchange on the library's exchange stream, beside the frames of the next batch.  No host-side
+    waits exist on the steady path: gsx_gather completes only the frames that render into the memory it ships, so the
+    exchange of a batch is posted `lag` frames late (lag = 2, the number of frames the library keeps in flight; less when
+    a batch is shorter) - by then the library has finished the batch's frames anyway - and a batch buffer is re-used by
+    frames queued BEHIND the exchange that reads it (the library makes them wait for it on the device).  Two batch buffers
+    alternate, so that on rank 0 the batch received last stays readable while the next one is filled.
 
-    def __init__(self, g, rank, world, frame_bytes, batch_frames, alloc):
+    Per frame i (0, 1, 2 ... of this rank): render into slot(i), then frame_done(i) once it is queued (any time before
+    frame i + 1 is rendered).  finish() posts what is left, a partial last batch included."""
+
+    def __init__(self, g, rank, world, frame_bytes, batch_frames, alloc, lag=2):
         """alloc(nbytes) -> (device pointer, keep-alive object)."""
         self.g, self.rank, self.world = g, rank, world
         self.frame_bytes, self.batch_frames = frame_bytes, batch_frames
+        self.lag = max(0, min(lag, batch_frames))     # (a batch's buffer is refilled 2 * batch_frames - lag ... frames later)
         nb = batch_frames * frame_bytes
         self.keep = []
         self.batches = []
@@ -157,12 +165,12 @@ class GsxFrameGather:
                 ptr, keep = alloc(nb * world)
                 self.recv[b] = ptr
                 self.keep.append(keep)
-        self.filled = [0, 0]          # frames rendered into the batch since its last gather
+        self.queued = 0               # frames queued so far
+        self.next_batch = 0           # first batch whose exchange has not been posted
         self.gathers = 0
 
     def slot(self, i):
         b, s = (i // self.batch_frames) % 2, i % self.batch_frames
-        self.filled[b] = s + 1
         return self.batches[b] + s * self.frame_bytes
 
     def _start(self, b):
@@ -172,17 +180,19 @@ class GsxFrameGather:
         size = [nb] * self.world
         root = self.rank == 0
         self.g.gather(self.batches[b], nb, self.recv[b] if root else None, off if root else None, size if root else None, 0)
-        self.filled[b] = 0
         self.gathers += 1
 
     def frame_done(self, i):
-        if i % self.batch_frames == self.batch_frames - 1:
-            self._start((i // self.batch_frames) % 2)
+        self.queued = max(self.queued, i + 1)
+        # batch k is complete with frame (k + 1) * batch_frames - 1 and posted `lag` frames later
+        while (self.next_batch + 1) * self.batch_frames - 1 + self.lag <= i:
+            self._start(self.next_batch % 2)
+            self.next_batch += 1
 
     def finish(self):
-        for b in range(2):
-            if self.filled[b]:
-                self._start(b)
+        while self.next_batch * self.batch_frames < self.queued:
+            self._start(self.next_batch % 2)
+            self.next_batch += 1
 
     def frame_on_rank0(self, b, r, s):
         """rank 0: device pointer of slot s of rank r's batch b as received last."""

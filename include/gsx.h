@@ -249,9 +249,14 @@ int gsx_comm_destroy(gsx_comm* comm);
 /* Every rank contributes send_bytes bytes at send_dev; on `root`, rank r's bytes land at recv_dev + recv_offsets[r]
  * (recv_bytes[r] of them; recv_bytes[r] must equal what rank r sends, recv_bytes[root] the root's own send_bytes).
  * recv_* are read on the root only.  With offsets = y0 * width * 4 the bands of one frame are gathered straight into
- * place; with offsets = r * frame_bytes * batch a batch of whole frames per rank.  Queued on the context's main stream
- * behind the frames already queued (they are completed first, which waits for them on the host), complete after
- * gsx_sync (or any wait on gsx_get_stream's stream) on the root. */
+ * place; with offsets = r * frame_bytes * batch a batch of whole frames per rank.
+ * The exchange runs on a stream of the context's own, beside the frames queued after it.  It is ordered behind (a) the
+ * queued frames that render into the memory it ships or fills — those are completed first, which waits for them on the
+ * host; frames queued into other memory stay in flight, so a caller that posts the exchange of a batch a frame or two late
+ * never waits — and (b), if gsx_get_stream has been called since the last exchange, everything on that stream at the time of the call.  A frame rendered later into memory
+ * an exchange still uses waits for it on the device.  The exchange is complete after gsx_sync, or behind any later
+ * gsx_get_stream; exchanges of one context run one after another in call order (every rank must post them in the same
+ * order).  The memory must stay valid until then. */
 int gsx_gather(gsx_ctx* ctx, gsx_comm* comm, const void* send_dev, uint64_t send_bytes, void* recv_dev,
                const uint64_t* recv_offsets, const uint64_t* recv_bytes, int root);
 
