@@ -13,6 +13,7 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -120,11 +121,15 @@ int gsx_comm_init(gsx_ctx* c, const void* id128, int rank, int nranks, gsx_comm*
     m->rank = rank;
     m->nranks = nranks;
     m->ctx = c;
-    if (nranks > 1) {     // (a single rank gathers from itself with a device copy and needs no RCCL)
+    // (a single rank gathers from itself with a device copy and needs no RCCL; GSX_COMM_FORCE_RCCL=1 in the environment makes
+    // it a real one-rank communicator whose gather is an RCCL send to itself: the one-GPU rehearsal of the exchange)
+    static const bool force_rccl = std::getenv("GSX_COMM_FORCE_RCCL") != nullptr;
+    if (nranks > 1 || force_rccl) {
         RcclApi* api = rccl();
         if (!api->handle) { c->err = api->error; delete m; return GSX_E_UNSUPPORTED; }
         ncclUniqueId id;
-        std::memcpy(id.internal, id128, GSX_COMM_ID_BYTES);
+        if (id128) std::memcpy(id.internal, id128, GSX_COMM_ID_BYTES);
+        else if (api->GetUniqueId(&id) != ncclSuccess) { c->err = "ncclGetUniqueId failed"; delete m; return GSX_E_HIP; }
         const ncclResult_t r = api->CommInitRank(&m->comm, nranks, id, rank);   // collective: returns when every rank has joined
         if (r != ncclSuccess) { c->err = std::string("ncclCommInitRank: ") + api->GetErrorString(r); delete m; return GSX_E_HIP; }
     }
@@ -187,7 +192,18 @@ int gsx_gather(gsx_ctx* c, gsx_comm* m, const void* send_dev, uint64_t send_byte
     rec.pending = false;
     if (is_root && send_bytes) {   // the root's own part never touches the network
         unsigned char* dst = static_cast<unsigned char*>(recv_dev) + recv_offsets[root];
-        if (dst != send_dev) GSX_HIP(c, hipMemcpyAsync(dst, send_dev, send_bytes, hipMemcpyDeviceToDevice, st));
+        if (dst == send_dev) {
+            // already in place
+        } else if (m->nranks == 1 && m->comm) {      // rehearsal (GSX_COMM_FORCE_RCCL): the same bytes through RCCL's send / recv kernels
+            RcclApi* api = rccl();
+            GSX_RCCL(c, api, api->GroupStart());
+            const ncclResult_t r1 = api->Recv(dst, send_bytes, ncclUint8, 0, m->comm, st);
+            const ncclResult_t r2 = r1 == ncclSuccess ? api->Send(send_dev, send_bytes, ncclUint8, 0, m->comm, st) : r1;
+            if (r2 != ncclSuccess) { (void)api->GroupEnd(); c->err = std::string("ncclSend/Recv to self: ") + api->GetErrorString(r2); return GSX_E_HIP; }
+            GSX_RCCL(c, api, api->GroupEnd());
+        } else {
+            GSX_HIP(c, hipMemcpyAsync(dst, send_dev, send_bytes, hipMemcpyDeviceToDevice, st));
+        }
     }
     if (m->nranks > 1) {
         RcclApi* api = rccl();
