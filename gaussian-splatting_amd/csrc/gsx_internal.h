@@ -152,6 +152,7 @@ struct GsxFrameSlot {
     bool hist_valid = false;           // tile_depth[depth_cur] describes a finished frame with the geometry below
     uint32_t hist_w = 0, hist_h = 0, hist_y0 = 0, hist_y1 = 0;
     float hist_wt[16] = {}, hist_proj[16] = {};
+    float hist_shade[4] = {};          // cutOff, cutOff * splatSize, bayerSize, bayerScale of that frame
     hipEvent_t frame_ev = nullptr;
     bool frame_pending = false;
 };

@@ -985,6 +985,7 @@ int gsx_launch_render(gsx_ctx* c, const gsx_uniforms* u, uint32_t w, uint32_t h,
     if ((rc = ensure(c, &c->accum, &c->accum_cap, static_cast<uint64_t>(n_tiles) * GSX_TILE_W * GSX_TILE_H)) != GSX_OK) return rc;
     // per-tile rank caps: usable when the slot's last frame had this geometry and the picture has moved by a few tiles at most
     int cap_radius = -1;
+    bool cap_exact = false;
     {
         const bool same = c->hist_valid && c->hist_w == w && c->hist_h == h && c->hist_y0 == y0 && c->hist_y1 == y1 &&
                           c->tile_depth[c->depth_cur] && c->tile_depth_cap[c->depth_cur] >= n_tiles;
@@ -1029,6 +1030,11 @@ int gsx_launch_render(gsx_ctx* c, const gsx_uniforms* u, uint32_t w, uint32_t h,
             if (ok) {
                 const int radius = 1 + static_cast<int>(ceilf(1.5f * moved / static_cast<float>(GSX_TILE_W)));
                 if (radius <= static_cast<int>(c->opt_caps_radius ? c->opt_caps_radius : 4u)) cap_radius = radius;
+                // Nothing the frame depends on has changed since the slot's last frame (a viewer at rest): every tile saturates at
+                // exactly the rank it did then, so the cap is that rank itself - no neighbourhood, no factor, no margin.  (If the
+                // caller did change something the matrices do not show, the redo continuation still completes the frame.)
+                const float shade[4] = {vp.cut, vp.cut_s, static_cast<float>(vp.bayer_size), vp.bayer_scale};
+                cap_exact = dmat == 0.0f && std::memcmp(shade, c->hist_shade, sizeof shade) == 0 && c->opt_tile_caps == 1;
             }
         }
     }
@@ -1072,7 +1078,8 @@ int gsx_launch_render(gsx_ctx* c, const gsx_uniforms* u, uint32_t w, uint32_t h,
     if (c->profiling) GSX_HIP(c, hipEventRecord(c->ev[EV_PROJ0], c->fstream));
     hipLaunchKernelGGL(k_frame_init, dim3(gsx_div_up(n_tiles, 256)), dim3(256), 0, c->fstream, c->ctl, c->m_perm + c->perm_cur, c->live_bits,
                        c->tile_state, vp.tiles_x, vp.tiles_y, c->aux, c->tile_depth[depth_prev], c->tile_depth[c->depth_cur], c->tile_band,
-                       cap_radius, c->opt_tile_caps == 2 ? 32u : 384u, c->opt_tile_caps == 2 ? 0u : 2048u);
+                       cap_exact ? 0 : cap_radius, cap_exact ? 256u : (c->opt_tile_caps == 2 ? 32u : 384u),
+                       (cap_exact || c->opt_tile_caps == 2) ? 0u : 2048u);
     if (f.caps_on)
         hipLaunchKernelGGL(k_band_masks, dim3(gsx_div_up(GSX_BANDS * vp.tiles_y * GSX_LIVE_ROW_WORDS, 256)), dim3(256), 0, c->fstream,
                            c->tile_band, vp.tiles_x, vp.tiles_y, c->band_masks);
@@ -1290,6 +1297,8 @@ int gsx_frame_finish_active(gsx_ctx* c) {
         c->hist_y0 = vp.y0; c->hist_y1 = vp.y1;
         std::memcpy(c->hist_wt, vp.wt, sizeof c->hist_wt);
         std::memcpy(c->hist_proj, vp.proj, sizeof c->hist_proj);
+        c->hist_shade[0] = vp.cut; c->hist_shade[1] = vp.cut_s;
+        c->hist_shade[2] = static_cast<float>(vp.bayer_size); c->hist_shade[3] = vp.bayer_scale;
         c->hist_valid = true;
     }
     c->frame_pending = false;
