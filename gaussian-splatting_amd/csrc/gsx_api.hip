@@ -680,7 +680,7 @@ int gsx_render(gsx_ctx* c, const gsx_uniforms* u, uint32_t width, uint32_t heigh
     return GSX_OK;
 }
 
-#ifdef GSX_DEBUG_COUNT
+#if defined(GSX_DEBUG_COUNT) || defined(GSX_DEBUG_TILETIME)
 int gsx_debug_read(gsx_ctx* c, int what, void* out, uint64_t bytes) {
     const void* src = nullptr;
     switch (what) {

@@ -184,12 +184,18 @@ __host__ __device__ __forceinline__ uint32_t gsx_band_lo(uint32_t j) {
     return (4u + sub) << (o - 2u);
 }
 
+// One launch per frame: clears the control block, the live-tile mask and the per-tile state, and - with rank caps - gives every
+// tile its cap band and builds the band masks.  A thread owns one tile POSITION of a row padded to 256 columns
+// (GSX_LIVE_ROW_WORDS x 32), so a wave holds exactly two mask words of one tile row and a band's mask is one ballot:
+// band_masks[j][ty][w] bit = tile (ty, 32 w + bit) wants ranks of band j, i.e. j < its cap band.
 __global__ __launch_bounds__(256) void k_frame_init(GsxFrameCtl* __restrict__ ctl, const uint32_t* __restrict__ m_ptr,
                                                     uint32_t* __restrict__ live_bits, uint32_t* __restrict__ tile_state,
                                                     uint32_t tiles_x, uint32_t tiles_y, uint32_t* __restrict__ aux,
                                                     const uint32_t* __restrict__ depth_prev, uint32_t* __restrict__ depth_cur,
-                                                    uint8_t* __restrict__ tile_band, int radius /* < 0: no caps */,
+                                                    uint8_t* __restrict__ tile_band, uint32_t* __restrict__ band_masks,
+                                                    int radius /* < 0: no caps */,
                                                     uint32_t cap_scale_q8 /* cap = depth * this / 256 */, uint32_t cap_margin) {
+    static_assert(GSX_LIVE_ROW_WORDS * 32 == 256 && GSX_BANDS == 64, "one 256-thread workgroup per tile row, one lane per band");
     const uint32_t lw = (tiles_x + 31u) / 32u, n_tiles = tiles_x * tiles_y;
     const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x, gsz = gridDim.x * blockDim.x;
     if (gtid < 64) aux[gtid] = 0u;
@@ -203,48 +209,50 @@ __global__ __launch_bounds__(256) void k_frame_init(GsxFrameCtl* __restrict__ ct
         const uint32_t w = i % lw, left = tiles_x - w * 32u;
         live_bits[i] = left >= 32u ? 0xFFFFFFFFu : ((1u << left) - 1u);
     }
-    for (uint32_t i = gtid; i < n_tiles; i += gsz) {
-        tile_state[i] = 0u;
-        depth_cur[i] = 0u;
-        if (radius < 0) continue;
-        // cap band of the tile: deepest retirement in the neighbourhood last frame; a neighbour that never retired lifts the cap
-        const int tx = static_cast<int>(i % tiles_x), ty = static_cast<int>(i / tiles_x);
-        uint32_t deepest = 0;
-        bool open_end = false;
-        for (int y = ty - radius; y <= ty + radius; ++y)
-            for (int x = tx - radius; x <= tx + radius; ++x) {
-                if (x < 0 || y < 0 || x >= static_cast<int>(tiles_x) || y >= static_cast<int>(tiles_y)) continue;
-                const uint32_t d = depth_prev[static_cast<uint32_t>(y) * tiles_x + static_cast<uint32_t>(x)];
-                open_end |= d == 0u;
-                deepest = d > deepest ? d : deepest;
-            }
-        uint32_t band = GSX_BAND_INF;
-        if (!open_end) {
-            const uint64_t cap = static_cast<uint64_t>(deepest) * cap_scale_q8 / 256u + cap_margin;   // x 1.5 + 2 K ranks by default
-            const uint64_t q = (cap + 1023u) >> 10;
-            if (q < (1ull << 31)) {
-                band = gsx_band_of(static_cast<uint32_t>(q));
-                if (gsx_band_lo(band) < q) ++band;           // round UP to a band boundary: ranks below R_band are wanted
-                if (band >= GSX_BANDS) band = GSX_BAND_INF;
-            }
+    const uint32_t lane = threadIdx.x & 63u;
+    for (uint32_t ty = blockIdx.x; ty < tiles_y; ty += gridDim.x) {      // (uniform per workgroup: the ballots below see whole waves)
+        const uint32_t tx = threadIdx.x;
+        const bool in_row = tx < tiles_x;
+        const uint32_t i = ty * tiles_x + tx;
+        uint32_t band = 0u;                                              // (positions past the row want nothing)
+        if (in_row) {
+            tile_state[i] = 0u;
+            depth_cur[i] = 0u;
         }
-        tile_band[i] = static_cast<uint8_t>(band);
+        if (radius < 0) continue;
+        if (in_row) {
+            // cap band of the tile: deepest retirement in the neighbourhood last frame; a neighbour that never retired lifts the cap
+            uint32_t deepest = 0;
+            bool open_end = false;
+            for (int y = static_cast<int>(ty) - radius; y <= static_cast<int>(ty) + radius; ++y)
+                for (int x = static_cast<int>(tx) - radius; x <= static_cast<int>(tx) + radius; ++x) {
+                    if (x < 0 || y < 0 || x >= static_cast<int>(tiles_x) || y >= static_cast<int>(tiles_y)) continue;
+                    const uint32_t d = depth_prev[static_cast<uint32_t>(y) * tiles_x + static_cast<uint32_t>(x)];
+                    open_end |= d == 0u;
+                    deepest = d > deepest ? d : deepest;
+                }
+            band = GSX_BAND_INF;
+            if (!open_end) {
+                const uint64_t cap = static_cast<uint64_t>(deepest) * cap_scale_q8 / 256u + cap_margin;   // x 1.5 + 2 K ranks by default
+                const uint64_t q = (cap + 1023u) >> 10;
+                if (q < (1ull << 31)) {
+                    band = gsx_band_of(static_cast<uint32_t>(q));
+                    if (gsx_band_lo(band) < q) ++band;           // round UP to a band boundary: ranks below R_band are wanted
+                    if (band >= GSX_BANDS) band = GSX_BAND_INF;
+                }
+            }
+            tile_band[i] = static_cast<uint8_t>(band);
+        }
+        // lane j keeps band j's ballot; the wave's 64 positions are mask words 2 * wave and 2 * wave + 1 of the row
+        uint64_t mine = 0;
+        for (uint32_t j = 0; j < GSX_BANDS; ++j) {
+            const uint64_t bal = __builtin_amdgcn_ballot_w64(j < band);
+            if (lane == j) mine = bal;
+        }
+        uint32_t* dst = band_masks + (static_cast<uint64_t>(lane) * tiles_y + ty) * GSX_LIVE_ROW_WORDS + (threadIdx.x >> 6) * 2u;
+        dst[0] = static_cast<uint32_t>(mine);
+        dst[1] = static_cast<uint32_t>(mine >> 32);
     }
-}
-
-// band_masks[j][ty][w] bit = tile (ty, 32 w + bit) wants ranks of band j, i.e. j < its cap band
-__global__ __launch_bounds__(256) void k_band_masks(const uint8_t* __restrict__ tile_band, uint32_t tiles_x, uint32_t tiles_y,
-                                                    uint32_t* __restrict__ band_masks) {
-    const uint32_t per_band = tiles_y * GSX_LIVE_ROW_WORDS;
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= GSX_BANDS * per_band) return;
-    const uint32_t j = i / per_band, r = i % per_band, ty = r / GSX_LIVE_ROW_WORDS, w = r % GSX_LIVE_ROW_WORDS;
-    uint32_t bits = 0;
-    for (uint32_t b = 0; b < 32u; ++b) {
-        const uint32_t tx = w * 32u + b;
-        if (tx < tiles_x && j < tile_band[ty * tiles_x + tx]) bits |= 1u << b;
-    }
-    band_masks[i] = bits;
 }
 
 // true if any tile of the inclusive box is still live.  s_live = one row of GSX_LIVE_ROW_WORDS (8) words per tile
@@ -659,6 +667,9 @@ __global__ __launch_bounds__(GSX_RASTER_NT) void k_raster(const uint16_t* __rest
 #ifdef GSX_DEBUG_COUNT
     unsigned long long dbg_shaded = 0, dbg_hits = 0, dbg_useful = 0;
 #endif
+#ifdef GSX_DEBUG_TILETIME     // (tools/tile_times.py: start / end of every retired tile on the 100 MHz wall clock, parked in its unused accumulators)
+    const unsigned long long dbg_t0 = wall_clock64();
+#endif
     gsx_f2 T = {in0 ? 1.0f : 0.0f, in1 ? 1.0f : 0.0f}, cr = {0.0f, 0.0f}, cg = {0.0f, 0.0f}, cb = {0.0f, 0.0f};
     float4* acc = accum + static_cast<uint64_t>(tile) * (GSX_TILE_W * GSX_TILE_H) + tid * 2;
     if (state == 1u) {
@@ -804,6 +815,10 @@ __global__ __launch_bounds__(GSX_RASTER_NT) void k_raster(const uint16_t* __rest
             if (!redo && cap < info[2]) { atomicAdd(&aux[17], 1u); atomicMin(&aux[18], static_cast<uint32_t>(cap >> 10)); }
         }
     } else if (tid == 0) {
+#ifdef GSX_DEBUG_TILETIME
+        reinterpret_cast<unsigned long long*>(accum + static_cast<uint64_t>(tile) * (GSX_TILE_W * GSX_TILE_H))[0] = dbg_t0;
+        reinterpret_cast<unsigned long long*>(accum + static_cast<uint64_t>(tile) * (GSX_TILE_W * GSX_TILE_H))[1] = wall_clock64();
+#endif
         tile_state[tile] = 2u;
         atomicAnd(&live_bits[tty * ((vp.tiles_x + 31u) / 32u) + (ttx >> 5)], ~(1u << (ttx & 31u)));
         atomicSub(&ctl->live_tiles, 1u);
@@ -1076,13 +1091,10 @@ int gsx_launch_render(gsx_ctx* c, const gsx_uniforms* u, uint32_t w, uint32_t h,
     // (K3, the projection, runs inside k_chunk_count on the ranks each iteration reaches)
     if (c->profiling && c->stat) GSX_HIP(c, hipMemsetAsync(c->stat, 0, GSX_STAT_BYTES, c->fstream));
     if (c->profiling) GSX_HIP(c, hipEventRecord(c->ev[EV_PROJ0], c->fstream));
-    hipLaunchKernelGGL(k_frame_init, dim3(gsx_div_up(n_tiles, 256)), dim3(256), 0, c->fstream, c->ctl, c->m_perm + c->perm_cur, c->live_bits,
+    hipLaunchKernelGGL(k_frame_init, dim3(vp.tiles_y), dim3(256), 0, c->fstream, c->ctl, c->m_perm + c->perm_cur, c->live_bits,
                        c->tile_state, vp.tiles_x, vp.tiles_y, c->aux, c->tile_depth[depth_prev], c->tile_depth[c->depth_cur], c->tile_band,
-                       cap_exact ? 0 : cap_radius, cap_exact ? 256u : (c->opt_tile_caps == 2 ? 32u : 384u),
+                       c->band_masks, cap_exact ? 0 : cap_radius, cap_exact ? 256u : (c->opt_tile_caps == 2 ? 32u : 384u),
                        (cap_exact || c->opt_tile_caps == 2) ? 0u : 2048u);
-    if (f.caps_on)
-        hipLaunchKernelGGL(k_band_masks, dim3(gsx_div_up(GSX_BANDS * vp.tiles_y * GSX_LIVE_ROW_WORDS, 256)), dim3(256), 0, c->fstream,
-                           c->tile_band, vp.tiles_x, vp.tiles_y, c->band_masks);
     if (c->profiling) GSX_HIP(c, hipEventRecord(c->ev[EV_PROJ1], c->fstream));
 
     // K4 + K5: near -> far iterations with geometrically growing rank windows.  Only as many ranks are scheduled

@@ -1,0 +1,43 @@
+"""Debug experiment (needs a -DGSX_DEBUG_TILETIME build of libgsx, GSX_LIB=tools/_dbg/libgsx_dbg.so): when every retired tile
+of the rasterizer started and ended (100 MHz wall clock, parked in the tile's unused accumulators) - is the launch bound by
+throughput or by its longest tiles?"""
+import ctypes as C, sys, os, importlib
+sys.path.insert(0, "tests"); sys.path.insert(0, "oracle")
+from conftest import load_pkg
+pkg = load_pkg()
+synth = importlib.import_module("gaussian_splatting_amd.synth")
+scene = importlib.import_module("gaussian_splatting_amd.scene")
+cam = importlib.import_module("gaussian_splatting_amd.camera")
+import numpy as np
+W, H = 1920, 1080
+NT = (W // 16) * ((H + 15) // 16)
+for name in sys.argv[1:] or ("clustered",):
+    raw = synth.SCENES[name](6_000_000); sp = scene.raw_to_splats(pkg, raw)
+    g = pkg.Gsx(0); g.upload(sp)
+    g.set_option("frames_in_flight", 1); g.set_option("async_sort", 0)
+    w = cam.orbit_pose(5.0, []); v, p, pos = cam.camera_matrices(w, 45.0, W / H)
+    for rep in range(4):
+        g.sort(pos, download=False)
+        g.render(pkg.make_uniforms(p, v), W, H, download=False); g.sync()
+        t = g.timings()
+        acc = np.zeros(NT * 256 * 4, np.float32)
+        st = np.zeros(NT + 2, np.uint32)
+        assert g.lib.gsx_debug_read(g.ctx, 13, acc.ctypes.data_as(C.c_void_p), C.c_uint64(acc.nbytes)) == 0
+        assert g.lib.gsx_debug_read(g.ctx, 10, st.ctypes.data_as(C.c_void_p), C.c_uint64(st.nbytes)) == 0
+        tt = acc.view(np.uint64).reshape(NT, 512)[:, :2]
+        ret = st[:NT] == 2
+        t0, t1 = tt[ret, 0].astype(np.int64), tt[ret, 1].astype(np.int64)
+        dur = (t1 - t0) / 100.0
+        span = (t1.max() - t0.min()) / 100.0
+        order = np.argsort(t1)
+        print(name, "rep", rep, "pairs", t["tile_pairs"], "iters", t["render_iters"], "retired", int(ret.sum()), "of", NT,
+              "| span us %.1f" % span, "| tile us: mean %.2f p50 %.2f p90 %.2f p99 %.2f max %.2f" % (dur.mean(), *np.percentile(dur, [50, 90, 99]), dur.max()),
+              "| busy tile-us / span %.1f" % (dur.sum() / span))
+        # how many tiles are still running in the last stretch of the launch
+        end = t1.max()
+        for back in (100, 50, 25, 10):
+            at = end - back * 100
+            print("    %3d us before the end: %4d tiles running, %4d not started" % (back, int(((t0 <= at) & (t1 > at)).sum()), int((t0 > at).sum())))
+        long = np.argsort(-dur)[:5]
+        print("    longest:", [(int(np.nonzero(ret)[0][i]), round(float(dur[i]), 1), round(float((t0[i] - t0.min()) / 100.0), 1)) for i in long], "(tile, us, start offset us)")
+    g.close()
