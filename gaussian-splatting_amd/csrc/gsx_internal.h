@@ -26,10 +26,26 @@
 #ifndef GSX_SORT_IPT
 #define GSX_SORT_IPT 12
 #endif
+#ifndef GSX_SORT_WPE
+#define GSX_SORT_WPE 4
+#endif
 #define GSX_SORT_TILE (GSX_SORT_NT * GSX_SORT_IPT)
 #define GSX_NOALLOC_MAX_KEYS GSX_SORT_NOALLOC_MAX   // gsx_sort_noalloc: largest selection its 20 MiB scratch array holds
+// The binner's pair sort (u16 tile id, u32 payload).  Measured on cfg 2 (A/B in one GPU call, ms per frame): 512 x 12 keys
+// per tile with LDS sized for 9-bit digits 0.404; 512 x 8 with registers cut for 5 waves per SIMD 0.394; 512 x 6 at 6 waves 0.400; 512 x 4 at 8 waves 0.396; 256 x 8 0.401.
+// (The depth sort's u32 tiles stay at 512 x 12: 512 x 8 takes 48 us per pass against 34.)
+#ifndef GSX_PAIR_NT
 #define GSX_PAIR_NT 512
-#define GSX_PAIR_IPT 12
+#endif
+#ifndef GSX_PAIR_IPT
+#define GSX_PAIR_IPT 8
+#endif
+#ifndef GSX_PAIR_MAXD
+#define GSX_PAIR_MAXD 512           // digits of a pair-sort pass at most (a frame of up to 512 tiles is sorted in one 9-bit pass)
+#endif
+#ifndef GSX_PAIR_WPE
+#define GSX_PAIR_WPE 5
+#endif
 #define GSX_PAIR_TILE (GSX_PAIR_NT * GSX_PAIR_IPT)
 
 // ---- raster geometry ----

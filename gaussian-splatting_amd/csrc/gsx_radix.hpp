@@ -209,8 +209,10 @@ __global__ __launch_bounds__(256) void k_radix_scan(uint32_t* __restrict__ cnt, 
 // write neighbouring columns, whose runs for a digit are adjacent in memory, and that XCD's L2 merges them into
 // whole lines before they leave the chip (measured: 100 MB -> 52 MB written per 6 M-key pass against one
 // two-tile range per block).  The next tile's keys are requested before the current tile is written out.
-template <typename KeyT, int NT, int IPT, bool IOTA_VALS>
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_radix_scatter(const KeyT* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
+// MAXD: digits the pass can have at most (LDS is sized for it: the pair sort's 6..8-bit digits leave room for a third
+// workgroup per CU); WPE: waves per SIMD the register budget is cut for.
+template <typename KeyT, int NT, int IPT, bool IOTA_VALS, int MAXD = GSX_RADIX_MAX_DIGITS, int WPE = 4>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_radix_scatter(const KeyT* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                                                       KeyT* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
                                                       const uint32_t* __restrict__ count_ptr, uint32_t shift, uint32_t bits,
                                                       const uint32_t* __restrict__ cnt_scanned, const uint32_t* __restrict__ totals,
@@ -219,8 +221,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     constexpr int TILE = NT * IPT;
     __shared__ KeyT s_keys[TILE];
     __shared__ uint32_t s_vals[TILE];
-    __shared__ uint32_t s_whist[NW][GSX_RADIX_MAX_DIGITS];   // per-wave digit counts, then wave prefixes + bin base
-    __shared__ uint32_t s_gofs[GSX_RADIX_MAX_DIGITS];        // global index = s_gofs[d] + LDS slot
+    __shared__ uint32_t s_whist[NW][MAXD];   // per-wave digit counts, then wave prefixes + bin base
+    __shared__ uint32_t s_gofs[MAXD];        // global index = s_gofs[d] + LDS slot
     __shared__ uint32_t s_tmp[NW];
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t nd = 1u << bits, mask = nd - 1u;
@@ -235,8 +237,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 
     // Thread t owns the PER consecutive digits t*PER .. t*PER+PER-1: their bases (exclusive scan of the digit
     // totals), the column's scanned counts and the running output offsets stay in its registers.
-    constexpr int PER = GSX_RADIX_MAX_DIGITS / NT > 0 ? GSX_RADIX_MAX_DIGITS / NT : 1;   // (threads past the last digit own none)
-    static_assert(PER * NT >= GSX_RADIX_MAX_DIGITS, "every digit needs an owner");
+    constexpr int PER = MAXD / NT > 0 ? MAXD / NT : 1;   // (threads past the last digit own none)
+    static_assert(PER * NT >= MAXD, "every digit needs an owner");
     KeyT key[IPT];
     uint32_t val[IPT];
     uint32_t col_cnt[PER], base[PER], run[PER];
@@ -273,7 +275,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     bool new_col = true;
 
     for (;;) {
-        for (uint32_t t = tid; t < NW * GSX_RADIX_MAX_DIGITS; t += NT) (&s_whist[0][0])[t] = 0;
+        for (uint32_t t = tid; t < NW * MAXD; t += NT) (&s_whist[0][0])[t] = 0;
         __syncthreads();   // also: previous tile's write-out has finished reading s_keys/s_vals/s_gofs
 
         // ---- rank inside the wave: ballots + one returning LDS add per (item, digit) ----

@@ -907,6 +907,8 @@ static int launch_iteration(gsx_ctx* c, uint32_t iter, uint32_t window, bool fir
     uint32_t tile_bits = 1;
     while ((1u << tile_bits) < f.n_tiles) ++tile_bits;
     const GsxRadixPlan plan = gsx_radix_plan(tile_bits);
+    for (int p = 0; p < plan.n_passes; ++p)
+        if ((1u << plan.bits[p]) > static_cast<uint32_t>(GSX_PAIR_MAXD)) { c->err = "pair sort digit wider than GSX_PAIR_MAXD"; return GSX_E_INTERNAL; }
     // grid: one round of resident workgroups (sized for the budget: the pair count is device-side)
     const uint32_t g = gsx_radix_blocks(c->pair_cap, GSX_PAIR_TILE, c->pair_slots);
     const uint32_t cols = gsx_radix_columns(c->pair_slots);
@@ -918,7 +920,7 @@ static int launch_iteration(gsx_ctx* c, uint32_t iter, uint32_t window, bool fir
                            count_ptr, plan.shift[p], plan.bits[p], cnt, static_cast<uint32_t>(GSX_PAIR_TILE), cols);
         hipLaunchKernelGGL((k_radix_scan<0>), dim3(1u << plan.bits[p]), dim3(256), 0, c->fstream, cnt, count_ptr,
                            static_cast<uint32_t>(GSX_PAIR_TILE), cols, totals);
-        hipLaunchKernelGGL((k_radix_scatter<uint16_t, GSX_PAIR_NT, GSX_PAIR_IPT, false>), dim3(g), dim3(GSX_PAIR_NT), 0, c->fstream,
+        hipLaunchKernelGGL((k_radix_scatter<uint16_t, GSX_PAIR_NT, GSX_PAIR_IPT, false, GSX_PAIR_MAXD, GSX_PAIR_WPE>), dim3(g), dim3(GSX_PAIR_NT), 0, c->fstream,
                            c->pair_key[cur], c->pair_val[cur], c->pair_key[cur ^ 1], c->pair_val[cur ^ 1], count_ptr, plan.shift[p],
                            plan.bits[p], cnt, totals, cols);
         cur ^= 1;
@@ -1319,6 +1321,6 @@ int gsx_frame_finish_active(gsx_ctx* c) {
 
 uint32_t gsx_pair_slots(int cus) {
     int per = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, k_radix_scatter<uint16_t, GSX_PAIR_NT, GSX_PAIR_IPT, false>, GSX_PAIR_NT, 0) != hipSuccess || per < 1) per = 2;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, k_radix_scatter<uint16_t, GSX_PAIR_NT, GSX_PAIR_IPT, false, GSX_PAIR_MAXD, GSX_PAIR_WPE>, GSX_PAIR_NT, 0) != hipSuccess || per < 1) per = 2;
     return static_cast<uint32_t>(cus) * static_cast<uint32_t>(per);
 }

@@ -211,10 +211,10 @@ static void launch_pass(gsx_ctx* c, hipStream_t st, uint32_t g, const KeyT* kin,
     hipLaunchKernelGGL((k_radix_scan<0>), dim3(1u << bits), dim3(256), 0, st, cnt, count_ptr, TILE, cols, totals);
     if (ev0) (void)hipEventRecord(ev0, st);
     if (iota)
-        hipLaunchKernelGGL((k_radix_scatter<KeyT, NT, IPT, true>), dim3(g), dim3(NT), 0, st, kin, vin, kout, vout, count_ptr, shift,
+        hipLaunchKernelGGL((k_radix_scatter<KeyT, NT, IPT, true, GSX_RADIX_MAX_DIGITS, GSX_SORT_WPE>), dim3(g), dim3(NT), 0, st, kin, vin, kout, vout, count_ptr, shift,
                            bits, cnt, totals, cols);
     else
-        hipLaunchKernelGGL((k_radix_scatter<KeyT, NT, IPT, false>), dim3(g), dim3(NT), 0, st, kin, vin, kout, vout, count_ptr, shift,
+        hipLaunchKernelGGL((k_radix_scatter<KeyT, NT, IPT, false, GSX_RADIX_MAX_DIGITS, GSX_SORT_WPE>), dim3(g), dim3(NT), 0, st, kin, vin, kout, vout, count_ptr, shift,
                            bits, cnt, totals, cols);
     if (ev1) (void)hipEventRecord(ev1, st);
 }
@@ -430,7 +430,7 @@ uint64_t gsx_sort_workspace_words(uint64_t) { return gsx_radix_workspace_words(G
 // Resident workgroups of the depth sort's scatter kernel on this device (CUs x blocks per CU).
 uint32_t gsx_sort_slots(int cus) {
     int per = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, k_radix_scatter<uint32_t, GSX_SORT_NT, GSX_SORT_IPT, false>, GSX_SORT_NT, 0) != hipSuccess || per < 1) per = 2;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, k_radix_scatter<uint32_t, GSX_SORT_NT, GSX_SORT_IPT, false, GSX_RADIX_MAX_DIGITS, GSX_SORT_WPE>, GSX_SORT_NT, 0) != hipSuccess || per < 1) per = 2;
     return static_cast<uint32_t>(cus) * static_cast<uint32_t>(per);
 }
 
