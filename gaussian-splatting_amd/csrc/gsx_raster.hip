@@ -568,7 +568,6 @@ __device__ __forceinline__ uint32_t gsx_wave_lower_bound(const uint16_t* __restr
 // ---------------------------------------------------------------------------
 #define GSX_RASTER_NT 128            // threads per tile: 2 waves x 64 lanes x 2 pixels
 #define GSX_RASTER_BATCH 128
-#define GSX_RASTER_CHECK 8           // a wave re-checks "all my pixels saturated" every this many shaded splats
 #ifndef GSX_T_EPS
 #define GSX_T_EPS (1.0f / 2048.0f)
 #endif
@@ -677,6 +676,7 @@ __global__ __launch_bounds__(GSX_RASTER_NT) void k_raster(const uint16_t* __rest
         cr = gsx_f2{a0.x, a1.x}; cg = gsx_f2{a0.y, a1.y}; cb = gsx_f2{a0.z, a1.z}; T = gsx_f2{a0.w, a1.w};
     }
     const float cut = vp.cut;
+    gsx_f2 cutT = {T.x >= GSX_T_EPS ? cut : -1.0f, T.y >= GSX_T_EPS ? cut : -1.0f};   // per-pixel hit threshold (see the shading loop)
     const uint32_t rank_hi = MODE == 2 ? info[2] - info[1] : 0u;   // m - cursor
     // pixel-centre rectangle of half 0; half w is offset by 8 rows
     const float tx0f = static_cast<float>(tx * GSX_TILE_W) + 0.5f, ty0f = static_cast<float>(ty * GSX_TILE_H) + 0.5f;
@@ -734,12 +734,18 @@ __global__ __launch_bounds__(GSX_RASTER_NT) void k_raster(const uint16_t* __rest
             // (readfirstlane returns int: convert each half to u32 BEFORE widening, or bit 31 sign-extends)
             const uint32_t mk_lo = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(static_cast<uint32_t>(mk))));
             const uint32_t mk_hi = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(static_cast<uint32_t>(mk >> 32))));
-            uint64_t mask = (static_cast<uint64_t>(mk_hi) << 32) | mk_lo;
-            while (mask) {
+            // The mask is walked in four 16-bit parts; before each part that holds a splat the wave asks whether all its 128
+            // pixels are saturated.  The walk is scalar code: the shading loop issues about as many scalar as vector
+            // instructions, and the CU's one scalar unit serves a SIMD once in four cycles - as often as its vector unit.
+#pragma unroll 1
+            for (uint32_t part = 0; part < 4u && wave_live; ++part) {
+                uint32_t bits = ((part & 2u ? mk_hi : mk_lo) >> ((part & 1u) * 16u)) & 0xFFFFu;
+                if (bits == 0u) continue;
                 if (__builtin_amdgcn_ballot_w64(T.x >= GSX_T_EPS || T.y >= GSX_T_EPS) == 0) { wave_live = false; break; }   // all 128 pixels saturated
-                for (int k = 0; k < GSX_RASTER_CHECK && mask; ++k) {
-                    const uint32_t j = w * 64u + static_cast<uint32_t>(__builtin_ctzll(mask));
-                    mask &= mask - 1;
+                const uint32_t jbase = w * 64u + part * 16u;
+                while (bits) {
+                    const uint32_t j = jbase + static_cast<uint32_t>(__builtin_ctz(bits));
+                    bits &= bits - 1u;
                     const float4 sa = s_a[j];
                     const float4 sm = s_m[j];
                     const gsx_f2 dx = fx - sa.x;
@@ -750,8 +756,9 @@ __global__ __launch_bounds__(GSX_RASTER_NT) void k_raster(const uint16_t* __rest
                     // function of (scene, permutation, uniforms): iteration windows, the history-driven schedule, the
                     // pair budget and the band a tile is rendered in only decide WHEN work is skipped, never what a
                     // pixel holds (skipped contribution < GSX_T_EPS per channel = 0.13/255).
-                    const bool h0 = fabsf(u.x) <= cut && fabsf(v.x) <= cut && T.x >= GSX_T_EPS,
-                               h1 = fabsf(u.y) <= cut && fabsf(v.y) <= cut && T.y >= GSX_T_EPS;
+                    // cutT = the quad's cutOff while the pixel is live, -1 once it is frozen: inside the quad AND live is
+                    // one max and one compare per pixel.  (Records are finite: gsx_project culls what is not.)
+                    const bool h0 = fmaxf(fabsf(u.x), fabsf(v.x)) <= cutT.x, h1 = fmaxf(fabsf(u.y), fabsf(v.y)) <= cutT.y;
 #ifdef GSX_DEBUG_COUNT
                     ++dbg_shaded;
                     dbg_hits += __popcll(__builtin_amdgcn_ballot_w64(h0)) + __popcll(__builtin_amdgcn_ballot_w64(h1));
@@ -777,6 +784,7 @@ __global__ __launch_bounds__(GSX_RASTER_NT) void k_raster(const uint16_t* __rest
                         const gsx_f2 wgt = T * alpha;
                         cr += wgt * c.x; cg += wgt * c.y; cb += wgt * c.z;
                         T -= wgt;  // T *= (1 - alpha)
+                        cutT = gsx_f2{T.x >= GSX_T_EPS ? cut : -1.0f, T.y >= GSX_T_EPS ? cut : -1.0f};
                     }
                 }
             }
