@@ -380,7 +380,11 @@ __global__ __launch_bounds__(GSX_CNT_NT) void k_chunk_count(const GsxFrameCtl* _
 __global__ __launch_bounds__(GSX_BIN_NT) void k_chunk_emit(const GsxFrameCtl* __restrict__ ctl, uint32_t tiles_x,
                                                            const uint32_t* __restrict__ block_sums, const uint32_t* __restrict__ sub_off,
                                                            const uint32_t* __restrict__ rank_box,
-                                                           uint16_t* __restrict__ pair_key, uint32_t* __restrict__ pair_val) {
+                                                           uint16_t* __restrict__ pair_key, uint32_t* __restrict__ pair_val
+#ifdef GSX_DEBUG_TILETIME
+                                                           , unsigned long long* __restrict__ dbg_slices
+#endif
+                                                           ) {
     constexpr uint32_t SUB = GSX_BIN_TILE / GSX_BIN_SUBS;        // 64 ranks
     constexpr uint32_t NW = GSX_BIN_NT / 64;
     static_assert(SUB == 64 && GSX_BIN_SUBS == 16, "one rank per lane, 17 sub offsets per block");
@@ -389,9 +393,17 @@ __global__ __launch_bounds__(GSX_BIN_NT) void k_chunk_emit(const GsxFrameCtl* __
     const uint32_t total = ctl->pairs, nbk = ctl->n_blocks;
     uint32_t* off = s_off[wave];
     uint32_t* sbx = s_box[wave];
-    for (uint64_t w = blockIdx.x * NW + wave; w * GSX_EMIT_SLICE < total; w += static_cast<uint64_t>(gridDim.x) * NW) {
+    // (slices are taken from the far end: behind the rank caps the last ones span a dozen nearly empty blocks, two dependent
+    //  loads each, and take 25-35 us against 8 for the rest - started first, they run beside the bulk instead of after it)
+    const uint64_t n_slices = (static_cast<uint64_t>(total) + GSX_EMIT_SLICE - 1u) / GSX_EMIT_SLICE;
+    for (uint64_t wi = blockIdx.x * NW + wave; wi < n_slices; wi += static_cast<uint64_t>(gridDim.x) * NW) {
+        const uint64_t w = n_slices - 1u - wi;
         const uint32_t s0 = static_cast<uint32_t>(w * GSX_EMIT_SLICE);
         const uint32_t s1 = (total - s0 < GSX_EMIT_SLICE) ? total : s0 + GSX_EMIT_SLICE;
+#ifdef GSX_DEBUG_TILETIME
+        const unsigned long long dbg_t0 = wall_clock64();
+        uint32_t dbg_visits = 0, dbg_blocks = 0;
+#endif
         // largest b with block_sums[b] <= s0 (block_sums[0] == 0; empty blocks share their successor's offset)
         uint32_t lo = 0, hi = nbk;
         while (hi - lo > 1u) {
@@ -404,6 +416,9 @@ __global__ __launch_bounds__(GSX_BIN_NT) void k_chunk_emit(const GsxFrameCtl* __
         }
         uint32_t cur = s0;
         for (uint32_t b = lo; b < nbk && cur < s1; ++b) {
+#ifdef GSX_DEBUG_TILETIME
+            ++dbg_blocks;
+#endif
             const uint32_t bbase = block_sums[b];
             const uint32_t so = lane <= GSX_BIN_SUBS ? sub_off[b * (GSX_BIN_SUBS + 1) + lane] : 0xFFFFFFFFu;
             const uint32_t blk_total = __shfl(so, GSX_BIN_SUBS);
@@ -415,6 +430,9 @@ __global__ __launch_bounds__(GSX_BIN_NT) void k_chunk_emit(const GsxFrameCtl* __
                 const uint32_t sub_base = bbase + __shfl(so, sb), sub_end = bbase + __shfl(so, sb + 1u);
                 if (sub_end <= cur) continue;                     // empty sub-block
                 if (sub_base >= s1) { cur = s1; break; }
+#ifdef GSX_DEBUG_TILETIME
+                ++dbg_visits;
+#endif
                 const uint32_t local = b * GSX_BIN_TILE + sb * SUB + lane;
                 const uint32_t box = rank_box[local];
                 const uint32_t cnt = box == GSX_RBOX_NONE ? 0u : (((box >> 16) & 0xFFu) + 1u) * ((box >> 24) + 1u);
@@ -448,6 +466,14 @@ __global__ __launch_bounds__(GSX_BIN_NT) void k_chunk_emit(const GsxFrameCtl* __
                 cur = sub_base + to;
             }
         }
+#ifdef GSX_DEBUG_TILETIME
+        if (lane == 0 && w < 65536u) {      // (tools/tile_times.py: start, end, sub-block visits | blocks << 32 of every slice)
+            dbg_slices[w * 4 + 0] = dbg_t0;
+            dbg_slices[w * 4 + 1] = wall_clock64();
+            dbg_slices[w * 4 + 2] = dbg_visits | (static_cast<unsigned long long>(dbg_blocks) << 32);
+            dbg_slices[w * 4 + 3] = 1;
+        }
+#endif
     }
 }
 
@@ -912,7 +938,11 @@ static int launch_iteration(gsx_ctx* c, uint32_t iter, uint32_t window, bool fir
         if (emit_grid > 4096u) emit_grid = 4096u;
         if (emit_grid < 1u) emit_grid = 1u;
         hipLaunchKernelGGL(k_chunk_emit, dim3(emit_grid), dim3(GSX_BIN_NT), 0, c->fstream, c->ctl, vp.tiles_x, c->scan_block_sums,
-                           c->sub_off, c->rank_box, c->pair_key[0], c->pair_val[0]);
+                           c->sub_off, c->rank_box, c->pair_key[0], c->pair_val[0]
+#ifdef GSX_DEBUG_TILETIME
+                           , reinterpret_cast<unsigned long long*>(c->accum) + (static_cast<uint64_t>(1) << 20)   // (8 MB into the accumulators: tiles 0 .. 2047 park there only while live)
+#endif
+                           );
     }
     // stable sort of the iteration's pairs by tile id; the pair count stays on the device
     const uint32_t* count_ptr = &c->ctl->pairs;

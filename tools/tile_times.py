@@ -38,6 +38,27 @@ for name in sys.argv[1:] or ("clustered",):
         for back in (100, 50, 25, 10):
             at = end - back * 100
             print("    %3d us before the end: %4d tiles running, %4d not started" % (back, int(((t0 <= at) & (t1 > at)).sum()), int((t0 > at).sum())))
+        # k_chunk_emit: one record per 512-pair slice, 8 MB into the accumulator array
+        sl = acc.view(np.uint64)[(1 << 20):(1 << 20) + 4 * 65536].reshape(-1, 4)
+        n_sl = (int(t["tile_pairs"]) + 511) // 512 if t["render_iters"] == 1 else 0
+        if n_sl:
+            sl = sl[:n_sl]
+            ok = (sl[:, 3] == 1) & (np.arange(n_sl) % 128 != 0)      # (every 128th record shares its line with a tile's stamps)
+            s0, s1 = sl[ok, 0].astype(np.int64), sl[ok, 1].astype(np.int64)
+            sd = (s1 - s0) / 100.0
+            vis, blks = (sl[ok, 2] & 0xFFFFFFFF).astype(np.int64), (sl[ok, 2] >> 32).astype(np.int64)
+            print("    emit: %d slices, span us %.1f | slice us: mean %.2f p50 %.2f p90 %.2f p99 %.2f max %.2f | visits mean %.1f max %d | blocks mean %.1f max %d"
+                  % (ok.sum(), (s1.max() - s0.min()) / 100.0, sd.mean(), *np.percentile(sd, [50, 90, 99]), sd.max(), vis.mean(), vis.max(), blks.mean(), blks.max()))
+            idx = np.nonzero(ok)[0]
+            slow = np.argsort(-sd)[:12]
+            print("      slowest slices (index, us, start offset us, visits, blocks):", [(int(idx[i]), round(float(sd[i]), 1), round(float((s0[i] - s0.min()) / 100.0), 1), int(vis[i]), int(blks[i])) for i in slow])
+            late = np.argsort(-s0)[:6]
+            print("      latest starts (index, start offset us, us):", [(int(idx[i]), round(float((s0[i] - s0.min()) / 100.0), 1), round(float(sd[i]), 1)) for i in late])
+            hist, edges = np.histogram(sd, bins=[0, 4, 8, 12, 16, 24, 32, 48, 64, 1000])
+            print("      slice us histogram:", list(zip([int(e) for e in edges[:-1]], [int(h) for h in hist])))
+            for lo, hi in ((0, 0.1), (0.1, 0.25), (0.25, 0.5), (0.5, 0.75), (0.75, 0.9), (0.9, 1.0)):
+                m = (idx >= lo * n_sl) & (idx < hi * n_sl)
+                print("      slices %3d%%-%3d%%: us mean %.2f max %.2f, visits mean %.1f, blocks mean %.1f, start offset us mean %.1f" % (lo * 100, hi * 100, sd[m].mean(), sd[m].max(), vis[m].mean(), blks[m].mean(), ((s0[m] - s0.min()) / 100.0).mean()))
         long = np.argsort(-dur)[:5]
         print("    longest:", [(int(np.nonzero(ret)[0][i]), round(float(dur[i]), 1), round(float((t0[i] - t0.min()) / 100.0), 1)) for i in long], "(tile, us, start offset us)")
     g.close()
