@@ -6,6 +6,9 @@
 #include <vector>
 
 #include "gsx_internal.h"
+#ifndef GSX_RADIX_MAX_BLOCKS
+#define GSX_RADIX_MAX_BLOCKS 2048
+#endif
 
 uint64_t gsx_sort_workspace_words(uint64_t cap);
 int gsx_launch_aabb(gsx_ctx* c);
@@ -214,6 +217,13 @@ int gsx_set_option(gsx_ctx* c, const char* name, uint64_t value) {
     } else if (!std::strcmp(name, "tile_caps_radius")) {
         if (value > 32) { c->err = "tile_caps_radius above 32"; return GSX_E_INVALID; }
         c->opt_caps_radius = value;
+    } else if (!std::strcmp(name, "sort_slots") || !std::strcmp(name, "pair_slots")) {
+        // workgroups the depth sort's / the pair sort's scatter kernels keep resident (default: as many as the GPU holds); fewer
+        // leave registers and LDS to the kernels of the other streams
+        if (value < 8 || value > GSX_RADIX_MAX_BLOCKS) { c->err = "sort_slots / pair_slots must be 8..2048"; return GSX_E_INVALID; }
+        int rc = set_device(c);
+        if (rc || (rc = gsx_frame_finish(c))) return rc;
+        (name[0] == 's' ? c->sort_slots : c->pair_slots) = static_cast<uint32_t>(value);
     } else if (!std::strcmp(name, "async_sort")) {
         c->opt_async_sort = value ? 1 : 0;
     } else if (!std::strcmp(name, "frames_in_flight")) {

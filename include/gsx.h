@@ -133,9 +133,13 @@ int gsx_get_sort_samples(gsx_ctx* ctx, double* sum_ms, uint32_t* sorts, int rese
  *                   second frame slot while frame k is still running; same pixels)
  *   "tile_caps"     0 = bin every live tile through the whole window (default 1: a tile is binned only up to 1.5 x the depth
  *                   at which it saturated in the frame slot's last frame, when the picture has moved by at most a few tiles
- *                   since; a tile that does not saturate after all gets the withheld pairs in a continuation; same pixels)
+ *                   since - exactly up to that depth when view and shading uniforms are unchanged; a tile that does not saturate after
+ *                   all gets the withheld pairs in a continuation; same pixels)
  *   "tile_caps_radius"  largest neighbourhood radius (in tiles, default 4, at most 32) up to which a moving view still uses the
  *                   rank caps; the radius needed follows from how far the scene moved on screen since the slot's last frame
+ *   "sort_slots", "pair_slots"  workgroups the scatter kernels of the depth sort / of the binner's pair sort keep resident
+ *                   (8 .. 2048; default: as many as the GPU holds, 512 on MI355X); fewer leave registers and LDS to the
+ *                   kernels of the context's other streams (measured: no gain)
  *   "lod_walk"      1 = cut an octree with the general kernels (every node tests itself, then walks its ancestor chain)
  *                   even when it is laid out in BFS order, for which the default is the top-down level-by-level cut;
  *                   same result, kept for A/B measurements and as the path for trees in any other order

@@ -339,6 +339,27 @@ def test_set_option_rejects_unknown(gsx_fresh, pkg):
         gsx.set_option("chunk_growth", 1)
 
 
+def test_scatter_slot_options_change_nothing(gsx_fresh, pkg, oracle, synth):
+    """gsx_set_option("sort_slots" | "pair_slots"): fewer resident scatter workgroups (longer column ranges in both radix
+    sorts) give the same permutation and the same frame, byte for byte; out-of-range values are rejected."""
+    gsx = gsx_fresh
+    w, h = 640, 360
+    splats = oracle.raw_to_splat(synth.clustered_cloud(300_000, seed=21))
+    view, proj, cam = camera(oracle, w, h)
+    u = pkg.make_uniforms(proj, view)
+    gsx.upload(splats)
+    want_perm = gsx.sort(cam).copy()
+    want = gsx.render(u, w, h).copy()
+    for ss, ps in ((8, 8), (24, 40), (2048, 2048)):
+        gsx.set_option("sort_slots", ss)
+        gsx.set_option("pair_slots", ps)
+        assert np.array_equal(gsx.sort(cam), want_perm), (ss, ps)
+        assert np.array_equal(gsx.render(u, w, h), want), (ss, ps)
+    for bad in (0, 7, 2049):
+        with pytest.raises(pkg.GsxError):
+            gsx.set_option("sort_slots", bad)
+
+
 def test_large_render_properties(gsx_fresh, pkg, oracle, synth):
     """cfg-2 size (6M splats, 1920x1080): the image oracle would take minutes, so check size-independent
     properties of the frame loop instead."""
