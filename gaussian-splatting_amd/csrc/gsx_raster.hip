@@ -650,7 +650,7 @@ __global__ __launch_bounds__(GSX_RASTER_NT) void k_raster(const uint16_t* __rest
     unsigned long long n_shades = 0, n_blends = 0, n_staged = 0;  // COUNT: (wave, splat) visits / pixels blended / pairs staged (wave 0)
     static_assert(GSX_RASTER_BATCH == GSX_RASTER_NT, "one staged splat per thread");
     __shared__ float4 s_a[GSX_RASTER_BATCH];  // cx cy ex ey
-    __shared__ float4 s_m[GSX_RASTER_BATCH];  // m00 m01 m10 m11
+    __shared__ float4 s_m[GSX_RASTER_BATCH];  // m00 m10 m01 m11
     __shared__ float4 s_c[GSX_RASTER_BATCH];  // r g b a
     __shared__ uint32_t s_rank[MODE == 2 ? GSX_RASTER_BATCH : 1];
     __shared__ uint64_t s_mask[NW][NW];        // [half][staging wave]: splats of the batch whose quad touches the half
@@ -702,7 +702,9 @@ __global__ __launch_bounds__(GSX_RASTER_NT) void k_raster(const uint16_t* __rest
         cr = gsx_f2{a0.x, a1.x}; cg = gsx_f2{a0.y, a1.y}; cb = gsx_f2{a0.z, a1.z}; T = gsx_f2{a0.w, a1.w};
     }
     const float cut = vp.cut;
-    gsx_f2 cutT = {T.x >= GSX_T_EPS ? cut : -1.0f, T.y >= GSX_T_EPS ? cut : -1.0f};   // per-pixel hit threshold (see the shading loop)
+    float cut_v = cut;                               // (kept in a vector register: the loop's select would re-copy the scalar every visit)
+    asm volatile("" : "+v"(cut_v));
+    gsx_f2 cutT = {T.x >= GSX_T_EPS ? cut_v : -1.0f, T.y >= GSX_T_EPS ? cut_v : -1.0f};   // per-pixel hit threshold (see the shading loop)
     const uint32_t rank_hi = MODE == 2 ? info[2] - info[1] : 0u;   // m - cursor
     // pixel-centre rectangle of half 0; half w is offset by 8 rows
     const float tx0f = static_cast<float>(tx * GSX_TILE_W) + 0.5f, ty0f = static_cast<float>(ty * GSX_TILE_H) + 0.5f;
@@ -730,7 +732,7 @@ __global__ __launch_bounds__(GSX_RASTER_NT) void k_raster(const uint16_t* __rest
             a = src[0]; m = src[1];
             float4 col = src[2];
             col.w = __builtin_amdgcn_logf(col.w);                // log2(opacity): folded into the exponent of the falloff (log2(0) = -inf -> alpha 0)
-            s_a[tid] = a; s_m[tid] = m; s_c[tid] = col;
+            s_a[tid] = a; s_m[tid] = make_float4(m.x, m.z, m.y, m.w); s_c[tid] = col;    // (m00 m10 | m01 m11: the dy terms of u and v are one packed multiply)
         }
         // (computed by every lane and masked with `valid` explicitly: lanes past the batch must
         // contribute 0 bits to the ballots below)
@@ -778,7 +780,8 @@ __global__ __launch_bounds__(GSX_RASTER_NT) void k_raster(const uint16_t* __rest
                     const float4 sm = s_m[j];
                     const gsx_f2 dx = fx - sa.x;
                     const float dy = fy - sa.y;
-                    const gsx_f2 u = sm.x * dx + sm.y * dy, v = sm.z * dx + sm.w * dy;
+                    const gsx_f2 tdy = gsx_f2{sm.z, sm.w} * dy;
+                    const gsx_f2 u = sm.x * dx + tdy.x, v = sm.y * dx + tdy.y;
                     // A pixel is FROZEN at the first splat that leaves its transmittance below GSX_T_EPS: nothing behind
                     // that splat contributes, whenever the wave / tile happens to stop.  This makes the frame a pure
                     // function of (scene, permutation, uniforms): iteration windows, the history-driven schedule, the
@@ -814,7 +817,7 @@ __global__ __launch_bounds__(GSX_RASTER_NT) void k_raster(const uint16_t* __rest
                         const gsx_f2 wgt = T * alpha;
                         cr += wgt * c.x; cg += wgt * c.y; cb += wgt * c.z;
                         T -= wgt;  // T *= (1 - alpha)
-                        cutT = gsx_f2{T.x >= GSX_T_EPS ? cut : -1.0f, T.y >= GSX_T_EPS ? cut : -1.0f};
+                        cutT = gsx_f2{T.x >= GSX_T_EPS ? cut_v : -1.0f, T.y >= GSX_T_EPS ? cut_v : -1.0f};
                     }
                 }
             }
