@@ -12,8 +12,8 @@ framebuffer (no readback).
 N > 1, two shardings over a replicated splat set:
   --shard views (default; weak scaling): a step is a batch of N views, one per rank.  Every rank renders the pose of
       the N = 1 run so that the per-GPU work is fixed (--distinct-views: rank r renders pose r of the pose set).  The
-      frames are rendered straight into the slots of a batch buffer and each full batch of 8 frames goes to rank 0 in
-      ONE gsx_gather (grouped RCCL send / recv on the library's exchange stream, beside the frames of the next batch)
+      frames are rendered straight into the slots of a batch buffer and each full batch (--gather-batch, default 1 frame)
+      goes to rank 0 in ONE gsx_gather (grouped RCCL send / recv on the library's exchange stream, beside the frames of the next batch)
       inside the timed region.
   --shard bands (strong scaling, BASELINE.json configs[4]): ONE 3840x2160 frame of the overlap-stress scene per step;
       rank r sorts the (replicated) scene and renders tile band r, the bands are gathered in place into rank 0's
@@ -171,7 +171,10 @@ def main():
     ap.add_argument("--gather", choices=("gsx", "torch", "none"), default="gsx")
     ap.add_argument("--no-gather", action="store_true", help="same as --gather none")
     ap.add_argument("--distinct-views", action="store_true", help="N > 1, views: rank r renders pose r instead of the N = 1 pose")
-    ap.add_argument("--gather-batch", type=int, default=8, help="frames per gather at N > 1 (views)")
+    ap.add_argument("--gather-batch", type=int, default=0,
+                    help="frames per gather at N > 1 (views); 0 = 1 for gsx_gather (the exchange stream overlaps every transfer with "
+                         "the next frames anyway, and a short run then ends with one frame's transfer exposed instead of a batch's), "
+                         "8 for the torch.distributed fallback (main-stream gathers)")
     ap.add_argument("--no-extras", action="store_true", help="skip the no-history / orbit / stage measurements after the timed region")
     ap.add_argument("--opt", action="append", default=[], help="name=value for gsx_set_option (A/B runs; not used by the driver)")
     a = ap.parse_args()
@@ -301,6 +304,8 @@ def main():
 
     fg = None      # view batches through gsx_gather
     bg = None      # view batches through torch.distributed
+    if a.gather_batch <= 0:
+        a.gather_batch = 1 if gather_kind == "gsx" else 8
     if not bands_mode and gather_kind == "gsx":
         fg = mg.GsxFrameGather(g, rank, world, fb_bytes, a.gather_batch, alloc)
     elif not bands_mode and gather_kind == "torch":
@@ -582,8 +587,11 @@ def main():
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     _dbg("closing")
-    if dist is not None:
-        dist.barrier()
+    if dist is not None:      # (a host word over gloo, like every other control collective: no NCCL communicator is created just to leave)
+        if pg == "nccl":
+            dist.barrier()
+        else:
+            dist.all_reduce(torch.zeros(1, dtype=torch.int32))
     g.close()
     if dist is not None:
         dist.destroy_process_group()
