@@ -393,13 +393,25 @@ __global__ __launch_bounds__(GSX_BIN_NT) void k_chunk_emit(const GsxFrameCtl* __
     const uint32_t total = ctl->pairs, nbk = ctl->n_blocks;
     uint32_t* off = s_off[wave];
     uint32_t* sbx = s_box[wave];
-    // (slices are taken from the far end: behind the rank caps the last ones span a dozen nearly empty blocks, two dependent
-    //  loads each, and take 25-35 us against 8 for the rest - started first, they run beside the bulk instead of after it)
-    const uint64_t n_slices = (static_cast<uint64_t>(total) + GSX_EMIT_SLICE - 1u) / GSX_EMIT_SLICE;
+    // Slices are taken from the far end, and the farthest eighth of the pairs is cut into slices of GSX_EMIT_SLICE / 8: behind
+    // the rank caps the last slices cross a dozen nearly empty blocks, two dependent loads each, and took 25-35 us against 8 for
+    // the rest (tools/tile_times.py) - started first and spread over eight times as many waves they end with the bulk.
+    constexpr uint32_t SMALL = GSX_EMIT_SLICE / 8u;
+    const uint32_t n_big = (total - total / 8u) / GSX_EMIT_SLICE;                 // slices of GSX_EMIT_SLICE from slot 0
+    const uint32_t big_end = n_big * GSX_EMIT_SLICE;
+    const uint32_t n_small = (total - big_end + SMALL - 1u) / SMALL;              // the rest, in slices of SMALL
+    const uint64_t n_slices = static_cast<uint64_t>(n_big) + n_small;
     for (uint64_t wi = blockIdx.x * NW + wave; wi < n_slices; wi += static_cast<uint64_t>(gridDim.x) * NW) {
-        const uint64_t w = n_slices - 1u - wi;
-        const uint32_t s0 = static_cast<uint32_t>(w * GSX_EMIT_SLICE);
-        const uint32_t s1 = (total - s0 < GSX_EMIT_SLICE) ? total : s0 + GSX_EMIT_SLICE;
+        uint32_t s0, s1;
+        if (wi < n_small) {                                                       // far end first
+            s0 = big_end + (n_small - 1u - static_cast<uint32_t>(wi)) * SMALL;
+            s1 = (total - s0 < SMALL) ? total : s0 + SMALL;
+        } else {
+            s0 = (n_big - 1u - static_cast<uint32_t>(wi - n_small)) * GSX_EMIT_SLICE;
+            s1 = s0 + GSX_EMIT_SLICE;
+        }
+        const uint64_t w = wi;      // (debug record index)
+        (void)w;
 #ifdef GSX_DEBUG_TILETIME
         const unsigned long long dbg_t0 = wall_clock64();
         uint32_t dbg_visits = 0, dbg_blocks = 0;
