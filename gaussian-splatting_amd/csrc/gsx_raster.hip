@@ -533,6 +533,9 @@ __global__ __launch_bounds__(1024) void k_chunk_scan(GsxFrameCtl* __restrict__ c
     if (threadIdx.x == 0) { s_carry = 0ull; s_fit = 0u; s_pairs = 0u; }
     __syncthreads();
     const bool dead = ctl->live_tiles == 0u;         // every count block wrote 0: the window is consumed whole
+    // (read here, beside the block sums, not in the tail)
+    const uint32_t cur = ctl->cursor[iter], m = ctl->m, tp = ctl->total_pairs, mp = ctl->max_pairs, used = ctl->iters_used,
+                   dead_at = ctl->dead_at;
     if (dead && threadIdx.x == 0) s_fit = nb;
     for (uint32_t b0 = 0; b0 < nb && !dead; b0 += 1024 * PER) {
         const unsigned long long carry = s_carry;
@@ -564,27 +567,28 @@ __global__ __launch_bounds__(1024) void k_chunk_scan(GsxFrameCtl* __restrict__ c
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        const uint32_t cur = ctl->cursor[iter], m = ctl->m;
+        // (every word of *ctl the tail needs was read at the top: behind a store to *ctl the compiler must assume the next load
+        //  aliases it, and five dependent round trips to L2 were a third of this kernel)
+        const uint32_t fit = s_fit, pairs = s_pairs;
         const uint32_t remaining = m - cur, win = window < remaining ? window : remaining;
-        const unsigned long long take64 = static_cast<unsigned long long>(s_fit) * GSX_BIN_TILE;
+        const unsigned long long take64 = static_cast<unsigned long long>(fit) * GSX_BIN_TILE;
         const uint32_t take = take64 < win ? static_cast<uint32_t>(take64) : win;
-        ctl->n_blocks = s_fit;
-        ctl->pairs = s_pairs;
+        ctl->n_blocks = fit;
+        ctl->pairs = pairs;
         aux[0] = cur;                                   // for k_raster, off the control block's line
         aux[1] = m;
-        aux[32] = s_pairs;                              // the iteration's pair count, cursor and m on a line of their own that no
+        aux[32] = pairs;                                // the iteration's pair count, cursor and m on a line of their own that no
         aux[33] = cur;                                  // atomic ever touches: k_raster reads them through a const pointer, i.e.
         aux[34] = m;                                    // with scalar loads that do not queue behind the retiring tiles' atomics
         aux[17] = 0u;                                   // tiles this iteration's rasterizer finds live although capped ...
         aux[18] = 0xFFFFFFFFu;                          // ... and the smallest of their caps (in 1024 ranks)
-        if (iter == 0u && cur == 0u) { aux[2] = s_pairs; aux[3] = take; }   // density of the nearest window, for the host's schedule
+        if (iter == 0u && cur == 0u) { aux[2] = pairs; aux[3] = take; }   // density of the nearest window, for the host's schedule
         ctl->cursor[iter + 1] = cur + take;
-        const uint32_t tp = ctl->total_pairs;
-        ctl->total_pairs = (tp + s_pairs < tp) ? 0xFFFFFFFFu : tp + s_pairs;
-        if (s_pairs > ctl->max_pairs) ctl->max_pairs = s_pairs;
-        if (s_pairs) ctl->iters_used += 1u;
+        ctl->total_pairs = (tp + pairs < tp) ? 0xFFFFFFFFu : tp + pairs;
+        if (pairs > mp) ctl->max_pairs = pairs;
+        if (pairs) ctl->iters_used = used + 1u;
         if (take == 0u && win != 0u) ctl->stall = 1u;   // the nearest block alone exceeds the budget
-        if (dead && ctl->dead_at == 0u) ctl->dead_at = cur + 1u;
+        if (dead && dead_at == 0u) ctl->dead_at = cur + 1u;
     }
 }
 
