@@ -25,7 +25,7 @@ Prints ONE JSON line on rank 0.  `value` = splats sorted (and drawn) per second 
 ranks.  Beside the headline (one pose, history-driven schedule) the line carries `ms_per_step_no_history` (same pose,
 every iteration pre-queued) and `ms_per_step_orbit` (120-frame orbit, a new pose every step) at N = 1.
 The depth sort of frame k+1 runs on a stream of its own beside the binning / rasterizing of frame k (include/gsx.h, option
-"async_sort").  `roofline` describes the radix scatter kernel (k_radix_scatter<u32>): inside the timed region every 4th
+"async_sort").  `roofline` describes the radix scatter kernel (k_radix_scatter<u32>): inside the timed region every 8th
 sort is a SAMPLED one — one of its scatter launches (pass rotating), or keys + sort as a whole, is bracketed by HIP events
 on the stream it runs on, and that sort runs on the main stream, not beside the rasterizer, so that the bracket measures
 the kernel itself rather than its share of a GPU it splits with another kernel; pass 0 reads no index array and is priced
@@ -244,7 +244,7 @@ def main():
     for o in a.opt:
         k, v = o.split("=")
         g.set_option(k, int(v))
-    g.set_profiling(2)          # sampled: in every 4th sort one k_radix_scatter launch (or the whole sort) carries HIP events
+    g.set_profiling(2)          # sampled: in every 8th sort one k_radix_scatter launch (or the whole sort) carries HIP events
     u_mine = pkg.make_uniforms(my_view[1], my_view[0])
     fb_bytes = W * H * 4
     bands = mg.shard_bands(H, max(world, 1))
@@ -523,8 +523,8 @@ def main():
                          "per_pass_bytes": [launch_bytes[p] for p in sorted(per_pass)],
                          "launches_per_step": n_pass, "launches_timed": int(launches),
                          "algorithmic_bytes_per_launch": sum_bytes / launches if launches else None,
-                         "note": "HIP events inside the timed region around one scatter launch of every 4th sort (pass rotating); the sampled sorts run on the main stream, "
-                                 "un-overlapped (the other 3 of 4 sorts run beside the previous frame's rasterizer, where the same launch takes ~2.4x as long: DESIGN.md 4.6); "
+                         "note": "HIP events inside the timed region around one scatter launch of every 8th sort (pass rotating); the sampled sorts run on the main stream, "
+                                 "un-overlapped (the other 7 of 8 sorts run beside the previous frame's rasterizer, where the same launch takes ~2.4x as long: DESIGN.md 4.6); "
                                  "pass 0 priced at 12 B/key, passes >= 1 at 16 B/key"},
         }
         if not bands_mode:
@@ -539,7 +539,7 @@ def main():
         if sort_n_timed:
             out["sort_only_ms"] = sort_ms_timed
             out["sort_only_samples"] = sort_n_timed
-            out["sort_only_note"] = "keys + sort bracketed as a whole by HIP events in every 16th frame INSIDE the timed region (a sampled sort: on the main stream, not overlapped)"
+            out["sort_only_note"] = "keys + sort bracketed as a whole by HIP events in every 32nd frame INSIDE the timed region (a sampled sort: on the main stream, not overlapped)"
             out["sort_only_splats_per_s"] = n / (sort_ms_timed * 1e-3)
             out["sort_only_bytes_per_splat"] = sort_bytes
             out["sort_only_hbm_frac"] = sort_bytes * n / (sort_ms_timed * 1e-3) / 1e9 / HBM_PEAK_GBS

@@ -12,7 +12,7 @@
 #define GSX_SAMPLE_RING 32
 #define GSX_PERM_RING 3           // permutation buffers: two frames in flight read two of them while the next sort fills the third
 #define GSX_SAMPLE_WHOLE 4
-#define GSX_SAMPLE_EVERY 4u       // profiling level 2 samples every 4th sort
+#define GSX_SAMPLE_EVERY 8u       // profiling level 2 samples every 8th sort by default (gsx_set_option "sample_every")
 #define GSX_GATHER_RING 4          // exchanges whose memory ranges are remembered (an older one still running is waited for on the host)
 #define GSX_LOD_MAX_LEVELS 48
 #define GSX_LOD_TOP_NODES 4096u      // nodes of the leading octree levels one workgroup walks in LDS     // sample slot of "keys + sort as a whole" (slots 0..3: the scatter launch of a radix pass)
@@ -178,7 +178,7 @@ struct gsx_ctx : GsxFrameSlot {
     hipStream_t stream = nullptr;
     std::string err;
     bool profiling = false;            // level 1: events around every stage
-    int prof_level = 0;                // 0 off, 1 all stages, 2 sampled (one scatter launch, or keys + sort as a whole, in every 4th sort)
+    int prof_level = 0;                // 0 off, 1 all stages, 2 sampled (one scatter launch, or keys + sort as a whole, in every opt_sample_every-th sort)
     uint32_t prof_frame = 0;           // sorts launched (rotates the sampled pass)
     int sampled_pass = -1;             // level 2: pass whose scatter launch carries events in the last sort
     // level 2 samples: a ring of event pairs, so frames can be queued back to back and the durations collected later
@@ -280,6 +280,7 @@ struct gsx_ctx : GsxFrameSlot {
     bool frame_done_rec[GSX_PERM_RING] = {};
     bool sorted_rec = false;              // ev_sorted has been recorded (behind the latest sort, on whichever stream it ran)
     uint64_t opt_frames_in_flight = 2;
+    uint32_t opt_sample_every = GSX_SAMPLE_EVERY;   // profiling level 2: every how many sorts one is a sampled (synchronous) one
     bool sort_join_pending = false;      // a sort was queued on sort_stream and the main stream has not waited for it yet
     bool main_dirty = true;              // the main stream holds work the next sort must see (selection, upload): record ev_pre
     bool pre_wait = false;               // ev_pre is recorded and the sort stream has not waited for it yet

@@ -250,14 +250,14 @@ static int launch_sort_in(gsx_ctx* c, const GsxSortBuffers& sb, hipStream_t st) 
     const GsxRadixPlan plan = gsx_radix_plan(top_bits ? LOW_BITS : total_bits);
     const uint32_t wide_mask = top_bits ? ~((1u << LOW_BITS) - 1u) : 0u;
     if (top_bits) GSX_HIP(c, hipMemsetAsync(&c->flags->wide_m, 0, sizeof(uint32_t), st));
-    // Profiling level 2 brackets ONE thing in every GSX_SAMPLE_EVERY-th sort with a pair of events from the ring, rotating:
+    // Profiling level 2 brackets ONE thing in every opt_sample_every-th sort with a pair of events from the ring, rotating:
     // the scatter launch of pass 0, 1, ..., and (slot GSX_SAMPLE_WHOLE) the whole of keys + sort, from before the key kernel
     // to behind the last pass.  A sampled sort runs on the main stream (gsx_launch_sort), i.e. NOT beside the previous
     // frame's rasterizer, so that the bracket measures the kernel and not its share of a GPU it has to split.
     int sampled_pass = -1;
     if (sb.with_events) {
-        if (c->prof_level == 2 && plan.n_passes > 0 && c->prof_frame % GSX_SAMPLE_EVERY == 0u) {
-            const uint32_t turn = (c->prof_frame / GSX_SAMPLE_EVERY) % (static_cast<uint32_t>(plan.n_passes) + 1u);
+        if (c->prof_level == 2 && plan.n_passes > 0 && c->prof_frame % c->opt_sample_every == 0u) {
+            const uint32_t turn = (c->prof_frame / c->opt_sample_every) % (static_cast<uint32_t>(plan.n_passes) + 1u);
             sampled_pass = turn == static_cast<uint32_t>(plan.n_passes) ? GSX_SAMPLE_WHOLE : static_cast<int>(turn);
         }
         c->sampled_pass = sampled_pass;
@@ -329,7 +329,7 @@ int gsx_launch_sort(gsx_ctx* c) {
     sb.m_copy = c->m_perm + target;
     // (with every stage bracketed by events - profiling level 1 - the stages run one after another on the main stream, and so
     // does a sort that carries a level-2 sample)
-    const bool sampled = c->prof_level == 2 && c->prof_frame % GSX_SAMPLE_EVERY == 0u;
+    const bool sampled = c->prof_level == 2 && c->prof_frame % c->opt_sample_every == 0u;
     const bool async = c->opt_async_sort && c->sort_stream && !c->profiling && !sampled;
     hipStream_t st = c->stream;
     if (async) {

@@ -104,7 +104,7 @@ const char* gsx_last_error(const gsx_ctx* ctx);
 int gsx_sync(gsx_ctx* ctx);
 /* 0 = no events (default).  1 = HIP events around every stage and every radix scatter launch
  * (gsx_get_timings fills all *_ms fields; the ~20 events cost tens of microseconds per frame).
- * 2 = sampled: in every 4th sort ONE thing is bracketed, rotating: the k_radix_scatter launch of pass 0, 1, ... of the
+ * 2 = sampled: in every 8th sort (option "sample_every") ONE thing is bracketed, rotating: the k_radix_scatter launch of pass 0, 1, ... of the
  * depth sort (scatter_ms = the latest such launch, scatter_sample says which pass), then keys + sort as a whole.  A sampled
  * sort runs on the main stream instead of beside the previous frame (see gsx_sort), so the bracket times the kernel, not
  * its share of a GPU it splits with the rasterizer.  The samples go through a ring of event pairs, so frames can be queued
@@ -137,6 +137,8 @@ int gsx_get_sort_samples(gsx_ctx* ctx, double* sum_ms, uint32_t* sorts, int rese
  *                   all gets the withheld pairs in a continuation; same pixels)
  *   "tile_caps_radius"  largest neighbourhood radius (in tiles, default 4, at most 32) up to which a moving view still uses the
  *                   rank caps; the radius needed follows from how far the scene moved on screen since the slot's last frame
+ *   "sample_every"  profiling level 2: every how many sorts one is a sampled one (default 8; a sampled sort runs on the main
+ *                   stream, beside nothing, so that its events time the kernel itself - which costs that frame the overlap)
  *   "sort_slots", "pair_slots"  workgroups the scatter kernels of the depth sort / of the binner's pair sort keep resident
  *                   (8 .. 2048; default: as many as the GPU holds, 512 on MI355X); fewer leave registers and LDS to the
  *                   kernels of the context's other streams (measured: no gain)
