@@ -133,6 +133,60 @@ def test_shard_helpers(pkg):
     assert mg.shard_bands(2160, 8)[0] == (0, 272)        # 135 tile rows over 8 ranks: 17,17,17,17,17,17,17,16
 
 
+def test_frame_gather_posts_exchanges_late_and_in_order(pkg):
+    """GsxFrameGather (the view-batch loop of bench.py at N > 1), on a recording stand-in for the library: the exchange of a
+    batch is posted `lag` = min(2, batch) frames after the batch is complete - by then the library has finished its frames, so
+    gsx_gather never waits on the host - always before the first frame that refills its buffer, in batch order, and finish()
+    posts what is left, a partial batch included."""
+    import importlib
+    mg = importlib.import_module("gaussian_splatting_amd.multigpu")
+
+    class Rec:
+        def __init__(self):
+            self.calls, self.base = [], 0x1000
+
+        def gather(self, send, nbytes, recv, off, size, root):
+            self.calls.append((send, nbytes, recv, None if off is None else list(off), root))
+
+        def alloc(self, nbytes):
+            p = self.base
+            self.base += (nbytes + 255) // 256 * 256
+            return p, None
+
+    FB = 64
+    for batch, frames in ((1, 5), (2, 9), (3, 7), (8, 20)):
+        for rank, world in ((0, 1), (0, 4), (3, 4)):
+            g = Rec()
+            fg = mg.GsxFrameGather(g, rank, world, FB, batch, g.alloc)
+            lag = min(2, batch)
+            assert fg.lag == lag
+            posted_at = {}                                  # batch index -> frame after which its exchange was posted
+            for i in range(frames):
+                slot = fg.slot(i)
+                b = (i // batch) % 2
+                assert slot == fg.batches[b] + (i % batch) * FB
+                # the buffer this frame is rendered into is not waiting for an exchange of an earlier batch
+                first_of_batch = (i // batch) * batch
+                if i == first_of_batch and i >= 2 * batch:
+                    assert (i // batch) - 2 in posted_at, (batch, i)
+                before = len(g.calls)
+                fg.frame_done(i)
+                for k in range(before, len(g.calls)):
+                    posted_at[k] = i
+                    assert i == (k + 1) * batch - 1 + lag     # exactly `lag` frames behind the batch's last frame
+            fg.finish()
+            n_batches = (frames + batch - 1) // batch
+            assert fg.gathers == len(g.calls) == n_batches
+            for k, (send, nbytes, recv, off, root) in enumerate(g.calls):
+                assert send == fg.batches[k % 2] and nbytes == batch * FB and root == 0
+                if rank == 0:
+                    assert recv == fg.recv[k % 2] and off == [r * batch * FB for r in range(world)]
+                else:
+                    assert recv is None and off is None
+            fg.finish()                                      # idempotent
+            assert len(g.calls) == n_batches
+
+
 def test_two_rank_gloo_view_and_band_sharding(tmp_path):
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
