@@ -568,7 +568,7 @@ def main():
         kr = kernel_rooflines_from_profile(n) if not bands_mode else None
         if kr:
             out["kernel_rooflines"] = kr
-        if a.cpu_frames > 0:
+        if a.cpu_frames > 0 and world == 1:                    # (the CPU baseline is an N = 1 figure: the other ranks would only wait for it)
             v, secs = cpu_baseline(splats, views, a.cpu_frames)
             out["cpu_baseline"] = {"value": v, "unit": "splats/s", "cores": 1, "kind": "port",
                                    "sample": f"{a.cpu_frames} consecutive frames of the full {n}-splat sortSplats "
