@@ -11,6 +11,7 @@
 #endif
 
 uint64_t gsx_sort_workspace_words(uint64_t cap);
+uint64_t gsx_sort2_ws_bytes(uint64_t cap);
 int gsx_launch_aabb(gsx_ctx* c);
 uint32_t gsx_sort_slots(int cus);
 uint32_t gsx_pair_slots(int cus);
@@ -64,6 +65,11 @@ int alloc_scene(gsx_ctx* c, uint64_t n) {
     c->sort_cap = n;
     c->sort_ws_words = gsx_sort_workspace_words(n);
     if ((rc = dev_alloc(c, &c->sort_ws, c->sort_ws_words))) return rc;
+    // two-pass depth sort: (key, index) pairs, their scratch twin, count / prefix matrices
+    if ((rc = dev_alloc(c, &c->s2_pairs, n)) || (rc = dev_alloc(c, &c->s2_scratch, n))) return rc;
+    c->s2_ws_bytes = gsx_sort2_ws_bytes(n);
+    if ((rc = dev_alloc(c, &c->s2_ws, c->s2_ws_bytes))) return rc;
+    c->s2_backoff = c->s2_backoff_len = 0;
     // LOD / list-selection scratch (flags padded for 16-byte vector loads)
     const uint64_t fl = (n + 15) / 16 * 16 + 16;
     if ((rc = dev_alloc(c, &c->lod_stop, fl)) || (rc = dev_alloc(c, &c->lod_emit, fl))) return rc;
@@ -96,8 +102,11 @@ int gsx_create(int device, gsx_ctx** out) {
     if (hipStreamCreateWithFlags(&c->sort_stream, hipStreamNonBlocking) != hipSuccess) return fail(GSX_E_HIP);
     if (hipStreamCreateWithFlags(&c->parked.fstream, hipStreamNonBlocking) != hipSuccess) return fail(GSX_E_HIP);
     c->fstream = c->stream;              // slot 0 queues its frames on the main stream
-    if (hipEventCreateWithFlags(&c->ev_sorted, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_pre, hipEventDisableTiming) != hipSuccess)
+    if (hipEventCreateWithFlags(&c->ev_sorted, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_pre, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_s2_stats, hipEventDisableTiming) != hipSuccess)
         return fail(GSX_E_HIP);
+    if (hipHostMalloc(reinterpret_cast<void**>(&c->s2_stats_host), 64, hipHostMallocDefault) != hipSuccess) return fail(GSX_E_NOMEM);
+    std::memset(c->s2_stats_host, 0, 64);
     for (int b = 0; b < GSX_PERM_RING; ++b)
         if (hipEventCreateWithFlags(&c->ev_frame_done[b], hipEventDisableTiming) != hipSuccess) return fail(GSX_E_HIP);
     c->sel_stream = c->stream;
@@ -159,6 +168,9 @@ int gsx_destroy(gsx_ctx* c) {
     for (int b = 0; b < 2; ++b) { dev_free(&c->keys[b]); dev_free(&c->vals[b]); }
     for (int b = 0; b < GSX_PERM_RING; ++b) dev_free(&c->perm[b]);
     dev_free(&c->sort_ws); dev_free(&c->aabb_dev); dev_free(&c->flags);
+    dev_free(&c->s2_pairs); dev_free(&c->s2_scratch); dev_free(&c->s2_ws);
+    if (c->s2_stats_host) { (void)hipHostFree(c->s2_stats_host); c->s2_stats_host = nullptr; }
+    if (c->ev_s2_stats) (void)hipEventDestroy(c->ev_s2_stats);
     dev_free(&c->stat);
     for (GsxFrameSlot* sl : {static_cast<GsxFrameSlot*>(c), &c->parked}) {
         for (int b = 0; b < 2; ++b) { dev_free(&sl->pair_key[b]); dev_free(&sl->pair_val[b]); }
@@ -228,6 +240,10 @@ int gsx_set_option(gsx_ctx* c, const char* name, uint64_t value) {
         if (value > 1024) { c->err = "sample_every above 1024"; return GSX_E_INVALID; }
         c->opt_sample_every = value ? static_cast<uint32_t>(value) : GSX_SAMPLE_EVERY;
         c->prof_frame = 0;
+    } else if (!std::strcmp(name, "sort_algo")) {
+        if (value > 2) { c->err = "sort_algo must be 0 (automatic), 1 (LSD passes) or 2 (two-pass whenever its plan allows)"; return GSX_E_INVALID; }
+        c->opt_sort_algo = value;
+        c->s2_backoff = c->s2_backoff_len = 0;
     } else if (!std::strcmp(name, "async_sort")) {
         c->opt_async_sort = value ? 1 : 0;
     } else if (!std::strcmp(name, "frames_in_flight")) {
@@ -324,11 +340,11 @@ int gsx_get_timings(gsx_ctx* c, gsx_timings* out) {
     }
     if (c->sorted_valid) {
         t.sort_passes = c->sort_passes;
-        t.sort_launches = 3 * c->sort_passes - 1;   // pass 0's count is fused into the key kernel
+        t.sort_launches = c->sort_launches;
         if (c->sort_gated) {                        // the gated top-digit pass: launched (+ its copy), executed only if a key needed it
             uint32_t wide = 0;
             GSX_HIP(c, hipMemcpy(&wide, &c->flags->wide_m, sizeof wide, hipMemcpyDeviceToHost));
-            t.sort_launches += 1;                   // the gated copy
+            t.sort_launches += 4;                   // its count, scan, scatter and the gated copy
             if (!wide) --t.sort_passes;
         }
     }

@@ -237,6 +237,18 @@ struct gsx_ctx : GsxFrameSlot {
     uint32_t* perm[GSX_PERM_RING] = {};
     uint32_t perm_cur = 0;             // perm[perm_cur] holds the latest permutation; the next sort writes perm[(perm_cur + 1) % GSX_PERM_RING]
     uint32_t* m_perm = nullptr;        // GSX_PERM_RING device words: size of the selection each permutation was sorted from
+    // two-pass depth sort (gsx_sort2.hpp): pair array, its scratch twin (oversized buckets only), count / prefix matrices
+    uint2* s2_pairs = nullptr;
+    uint2* s2_scratch = nullptr;
+    unsigned char* s2_ws = nullptr;
+    uint64_t s2_ws_bytes = 0;
+    struct Gsx2Stats* s2_stats_host = nullptr;   // pinned: bucket statistics of the latest two-pass sort (copied behind it)
+    hipEvent_t ev_s2_stats = nullptr;
+    bool s2_stats_rec = false;
+    uint32_t s2_backoff = 0, s2_backoff_len = 0;   // sorts left on the LSD passes after a sort that sent many keys through k2_big / length of the next pause
+    uint64_t opt_sort_algo = 0;                    // 0 automatic, 1 LSD passes only, 2 two-pass whenever its plan allows (any size)
+    bool sort_two_pass = false;                    // the latest depth sort ran the two-pass form
+    uint32_t sort_launches = 0;
     uint32_t sort_passes = 0;
     bool sort_gated = false;   // the latest depth sort queued a gated top-digit pass (counted in sort_passes)
     uint32_t sort_slots = 1024, pair_slots = 1024;   // resident workgroups of the scatter kernels (CUs x blocks/CU)
@@ -340,6 +352,13 @@ __device__ __forceinline__ float gsx_sub(float a, float b) {
 }
 __device__ __forceinline__ float gsx_div(float a, float b) { return a / b; }
 __device__ __forceinline__ float gsx_sqrt(float a) { return sqrtf(a); }
+// glm::distance(position, cameraPos) = sqrt((dx*dx + dy*dy) + dz*dz), d = cameraPos - position (glm/detail/func_geometric.inl:8-23,47-55)
+__device__ __forceinline__ float gsx_distance(float4 p, float cx, float cy, float cz) {
+    const float dx = gsx_sub(cx, p.x), dy = gsx_sub(cy, p.y), dz = gsx_sub(cz, p.z);
+    const float d2 = gsx_add(gsx_add(gsx_mul(dx, dx), gsx_mul(dy, dy)), gsx_mul(dz, dz));
+    return gsx_sqrt(d2);
+}
+__device__ __forceinline__ uint32_t gsx_key_from_distance(float d) { return (~__float_as_uint(d)) & 0x7FFFFFFFu; }
 #endif
 
 static inline uint32_t gsx_div_up(uint64_t a, uint64_t b) { return static_cast<uint32_t>((a + b - 1) / b); }

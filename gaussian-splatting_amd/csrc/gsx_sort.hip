@@ -5,8 +5,11 @@
 // per-frame index upload (SplatMesh.h:56-57).
 #include "gsx_internal.h"
 #include "gsx_radix.hpp"
+#include "gsx_sort2.hpp"
 
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 // ---------------------------------------------------------------------------
@@ -49,12 +52,7 @@ int gsx_launch_upload(gsx_ctx* c, const void* aos80_dev, uint64_t n) {
 // u32 key = bit-complement of the (non-negative) float, top bit cleared, so a
 // stable ascending radix sort yields distance descending, index ascending.
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ float gsx_distance(float4 p, float cx, float cy, float cz) {
-    const float dx = gsx_sub(cx, p.x), dy = gsx_sub(cy, p.y), dz = gsx_sub(cz, p.z);
-    const float d2 = gsx_add(gsx_add(gsx_mul(dx, dx), gsx_mul(dy, dy)), gsx_mul(dz, dz));
-    return gsx_sqrt(d2);
-}
-__device__ __forceinline__ uint32_t gsx_key_from_distance(float d) { return (~__float_as_uint(d)) & 0x7FFFFFFFu; }
+// (gsx_distance / gsx_key_from_distance: gsx_internal.h, shared with the two-pass sort of gsx_sort2.hpp)
 
 // ---------------------------------------------------------------------------
 // K1: depth keys of the selection + the digit counts of radix pass 0 (fused H0).
@@ -228,6 +226,7 @@ struct GsxSortBuffers {
     uint64_t ws_words;
     uint32_t* result;
     bool with_events;      // profiling events / sampled scatter launches (the context's own sort only)
+    bool two_pass_ok = false;   // the context's pair arrays may be used (the context's own sort only)
     uint32_t* m_copy = nullptr;   // device word that receives the selection's size (the context's own sort only)
 };
 
@@ -250,15 +249,34 @@ static int launch_sort_in(gsx_ctx* c, const GsxSortBuffers& sb, hipStream_t st) 
     const GsxRadixPlan plan = gsx_radix_plan(top_bits ? LOW_BITS : total_bits);
     const uint32_t wide_mask = top_bits ? ~((1u << LOW_BITS) - 1u) : 0u;
     if (top_bits) GSX_HIP(c, hipMemsetAsync(&c->flags->wide_m, 0, sizeof(uint32_t), st));
+    // The two-pass form (gsx_sort2.hpp: one wide partition + one kernel that finishes every bucket in LDS) when its plan
+    // allows; the LSD passes below otherwise (small sorts, narrow key ranges, gsx_sort_noalloc) and for a while after a
+    // sort whose buckets were too dense for LDS (history, checked without waiting).
+    Gsx2Plan p2;
+    if (sb.two_pass_ok && c->s2_pairs && c->opt_sort_algo != 1) {
+        if (c->s2_stats_rec && hipEventQuery(c->ev_s2_stats) == hipSuccess) {
+            c->s2_stats_rec = false;
+            if (getenv("GSX_DEBUG_SORT2")) fprintf(stderr, "[gsx] two-pass stats: big_buckets %u big_keys %u max_bucket %u (cap %u)\n", c->s2_stats_host->big_buckets, c->s2_stats_host->big_keys, c->s2_stats_host->max_bucket, cap);
+            if (static_cast<uint64_t>(c->s2_stats_host->big_keys) * 64ull > cap) {
+                c->s2_backoff_len = c->s2_backoff_len ? (c->s2_backoff_len < 512u ? c->s2_backoff_len * 2u : 1024u) : 16u;
+                c->s2_backoff = c->s2_backoff_len;
+            } else if (c->s2_stats_host->big_keys == 0) {
+                c->s2_backoff_len = 0;
+            }
+        }
+        p2 = gsx2_plan(top_bits ? (1u << LOW_BITS) - 1u : key_span, cap, c->n, 0, c->opt_sort_algo == 2);
+        if (p2.ok && c->opt_sort_algo == 0 && c->s2_backoff) { --c->s2_backoff; p2.ok = false; }
+    }
+    const int n_stage = p2.ok ? 2 : plan.n_passes;    // launches a level-2 sample can bracket: radix passes, or partition + bucket sort
     // Profiling level 2 brackets ONE thing in every opt_sample_every-th sort with a pair of events from the ring, rotating:
     // the scatter launch of pass 0, 1, ..., and (slot GSX_SAMPLE_WHOLE) the whole of keys + sort, from before the key kernel
     // to behind the last pass.  A sampled sort runs on the main stream (gsx_launch_sort), i.e. NOT beside the previous
     // frame's rasterizer, so that the bracket measures the kernel and not its share of a GPU it has to split.
     int sampled_pass = -1;
     if (sb.with_events) {
-        if (c->prof_level == 2 && plan.n_passes > 0 && c->prof_frame % c->opt_sample_every == 0u) {
-            const uint32_t turn = (c->prof_frame / c->opt_sample_every) % (static_cast<uint32_t>(plan.n_passes) + 1u);
-            sampled_pass = turn == static_cast<uint32_t>(plan.n_passes) ? GSX_SAMPLE_WHOLE : static_cast<int>(turn);
+        if (c->prof_level == 2 && n_stage > 0 && c->prof_frame % c->opt_sample_every == 0u) {
+            const uint32_t turn = (c->prof_frame / c->opt_sample_every) % (static_cast<uint32_t>(n_stage) + 1u);
+            sampled_pass = turn == static_cast<uint32_t>(n_stage) ? GSX_SAMPLE_WHOLE : static_cast<int>(turn);
         }
         c->sampled_pass = sampled_pass;
         ++c->prof_frame;
@@ -273,6 +291,56 @@ static int launch_sort_in(gsx_ctx* c, const GsxSortBuffers& sb, hipStream_t st) 
     }
     if (sampled_pass == GSX_SAMPLE_WHOLE) GSX_HIP(c, hipEventRecord(samp0, st));
     if (profiling) GSX_HIP(c, hipEventRecord(c->ev[EV_KEY0], st));
+    uint32_t cur = 0;
+    uint32_t* result = sb.result;
+    if (p2.ok) {
+        const Gsx2Workspace w = gsx2_ws_carve(c->s2_ws, c->sort_cap);
+        uint32_t* keys_out = top_bits ? sb.keys[1] : nullptr;     // the gated pass wants the sorted keys beside the permutation
+        if (c->sel_iota)
+            hipLaunchKernelGGL(k2_keygen_hist<true>, dim3(p2.ncols), dim3(GSX2_NT), 0, st, c->pos4, nullptr, c->m_dev, c->cam[0], c->cam[1],
+                               c->cam[2], key_lo, key_span, p2.low_mask, p2.r, p2.nd, wide_mask, sb.keys[0], w.cnt, c->flags, sb.m_copy, w.stats);
+        else
+            hipLaunchKernelGGL(k2_keygen_hist<false>, dim3(p2.ncols), dim3(GSX2_NT), 0, st, c->pos4, c->sel_idx, c->m_dev, c->cam[0], c->cam[1],
+                               c->cam[2], key_lo, key_span, p2.low_mask, p2.r, p2.nd, wide_mask, sb.keys[0], w.cnt, c->flags, sb.m_copy, w.stats);
+        if (profiling) GSX_HIP(c, hipEventRecord(c->ev[EV_KEY1], st));
+        hipLaunchKernelGGL(k2_scan, dim3(p2.nd / 16), dim3(512), 0, st, w.cnt, w.pre, w.totals, p2.nd, p2.ncols);
+        hipEvent_t e0 = profiling ? c->ev[EV_X0] : (sampled_pass == 0 ? samp0 : nullptr);
+        hipEvent_t e1 = profiling ? c->ev[EV_X0 + 1] : (sampled_pass == 0 ? samp1 : nullptr);
+        if (e0) GSX_HIP(c, hipEventRecord(e0, st));
+        if (c->sel_iota)
+            hipLaunchKernelGGL(k2_partition<true>, dim3(p2.ncols), dim3(GSX2_PNT), 0, st, sb.keys[0], nullptr, c->m_dev, p2.low_mask, p2.r, p2.nd,
+                               w.cnt, w.pre, w.totals, w.base, c->s2_pairs, w.stats, c->flags);
+        else
+            hipLaunchKernelGGL(k2_partition<false>, dim3(p2.ncols), dim3(GSX2_PNT), 0, st, sb.keys[0], c->sel_idx, c->m_dev, p2.low_mask, p2.r,
+                               p2.nd, w.cnt, w.pre, w.totals, w.base, c->s2_pairs, w.stats, c->flags);
+        if (e1) GSX_HIP(c, hipEventRecord(e1, st));
+        e0 = profiling ? c->ev[EV_X0 + 2] : (sampled_pass == 1 ? samp0 : nullptr);
+        e1 = profiling ? c->ev[EV_X0 + 3] : (sampled_pass == 1 ? samp1 : nullptr);
+        if (e0) GSX_HIP(c, hipEventRecord(e0, st));
+        if (top_bits) {
+            hipLaunchKernelGGL((k2_local<GSX2_IPT, true>), dim3(p2.nd), dim3(GSX2_NT), 0, st, c->s2_pairs, w.base, p2.nd, p2.r, p2.q_min, p2.q, p2.idx_bits,
+                               result, keys_out, w.big_list, w.stats, c->flags);
+            hipLaunchKernelGGL((k2_local<8, true>), dim3(p2.nd), dim3(GSX2_NT), 0, st, c->s2_pairs, w.base, p2.nd, p2.r, p2.q_min, p2.q, p2.idx_bits, result,
+                               keys_out, w.big_list, w.stats, c->flags);
+            hipLaunchKernelGGL(k2_big<true>, dim3(256), dim3(GSX2_NT), 0, st, c->s2_pairs, c->s2_scratch, w.base, p2.r, p2.idx_bits, result, keys_out,
+                               w.big_list, w.stats);
+        } else {
+            hipLaunchKernelGGL((k2_local<GSX2_IPT, false>), dim3(p2.nd), dim3(GSX2_NT), 0, st, c->s2_pairs, w.base, p2.nd, p2.r, p2.q_min, p2.q, p2.idx_bits,
+                               result, keys_out, w.big_list, w.stats, c->flags);
+            hipLaunchKernelGGL((k2_local<8, false>), dim3(p2.nd), dim3(GSX2_NT), 0, st, c->s2_pairs, w.base, p2.nd, p2.r, p2.q_min, p2.q, p2.idx_bits, result,
+                               keys_out, w.big_list, w.stats, c->flags);
+            hipLaunchKernelGGL(k2_big<false>, dim3(256), dim3(GSX2_NT), 0, st, c->s2_pairs, c->s2_scratch, w.base, p2.r, p2.idx_bits, result, keys_out,
+                               w.big_list, w.stats);
+        }
+        if (e1) GSX_HIP(c, hipEventRecord(e1, st));
+        // bucket statistics for the next sorts' choice of form (read when the copy has landed, never waited for)
+        if (!c->s2_stats_rec) {
+            GSX_HIP(c, hipMemcpyAsync(c->s2_stats_host, w.stats, sizeof(Gsx2Stats), hipMemcpyDeviceToHost, st));
+            GSX_HIP(c, hipEventRecord(c->ev_s2_stats, st));
+            c->s2_stats_rec = true;
+        }
+        cur = 1;      // (the gated pass reads keys[1] + the permutation)
+    } else {
     if (c->sel_iota)
         hipLaunchKernelGGL(k_keygen_hist0<true>, dim3(g), dim3(GSX_SORT_NT), 0, st, c->pos4, nullptr, c->m_dev, c->cam[0],
                            c->cam[1], c->cam[2], key_lo, key_span, plan.shift[0], plan.bits[0], wide_mask, sb.keys[0], sb.ws, cols,
@@ -282,8 +350,6 @@ static int launch_sort_in(gsx_ctx* c, const GsxSortBuffers& sb, hipStream_t st) 
                            c->cam[1], c->cam[2], key_lo, key_span, plan.shift[0], plan.bits[0], wide_mask, sb.keys[0], sb.ws, cols,
                            c->flags, sb.m_copy);
     if (profiling) GSX_HIP(c, hipEventRecord(c->ev[EV_KEY1], st));
-    uint32_t cur = 0;
-    uint32_t* result = sb.result;
     for (int p = 0; p < plan.n_passes; ++p) {
         const bool first = p == 0, last = p + 1 == plan.n_passes;
         hipEvent_t e0 = profiling ? c->ev[EV_X0 + 2 * p] : (sampled_pass == p ? samp0 : nullptr);
@@ -292,6 +358,7 @@ static int launch_sort_in(gsx_ctx* c, const GsxSortBuffers& sb, hipStream_t st) 
                                                           last ? result : sb.vals[cur ^ 1], c->m_dev, plan.shift[p], plan.bits[p], sb.ws,
                                                           cols, /*need_hist=*/!first, /*iota=*/first && c->sel_iota, e0, e1);
         cur ^= 1;
+    }
     }
     if (top_bits) {   // gated top digit: result -> scratch values, then back (all four kernels see count 0 in the common case)
         static_assert(EV_X0 + 2 * 3 + 1 < EV_X_END, "event slots of the gated pass");
@@ -305,8 +372,10 @@ static int launch_sort_in(gsx_ctx* c, const GsxSortBuffers& sb, hipStream_t st) 
     if (profiling) GSX_HIP(c, hipEventRecord(c->ev[EV_SORT1], st));
     GSX_HIP(c, hipGetLastError());
     if (sb.with_events) {   // (the context's own sort: what gsx_get_timings reports)
-        c->sort_passes = static_cast<uint32_t>(plan.n_passes) + (top_bits ? 1u : 0u);   // (the gated pass counts as launched)
+        c->sort_passes = static_cast<uint32_t>(n_stage) + (top_bits ? 1u : 0u);   // (the gated pass counts as launched)
         c->sort_gated = top_bits != 0;
+        c->sort_two_pass = p2.ok;
+        c->sort_launches = p2.ok ? 6u : 3u * static_cast<uint32_t>(plan.n_passes) - 1u;   // (pass 0's count is fused into the key kernel)
     }
     return GSX_OK;
 }
@@ -326,6 +395,7 @@ int gsx_launch_sort(gsx_ctx* c) {
     const uint32_t target = (c->perm_cur + 1u) % GSX_PERM_RING;
     sb.result = c->perm[target];
     sb.with_events = true;
+    sb.two_pass_ok = true;
     sb.m_copy = c->m_perm + target;
     // (with every stage bracketed by events - profiling level 1 - the stages run one after another on the main stream, and so
     // does a sort that carries a level-2 sample)
@@ -426,6 +496,7 @@ int gsx_launch_keys_only(gsx_ctx* c, float* dist_dev) {
 }
 
 uint64_t gsx_sort_workspace_words(uint64_t) { return gsx_radix_workspace_words(GSX_RADIX_MAX_BLOCKS); }
+uint64_t gsx_sort2_ws_bytes(uint64_t cap) { return gsx2_ws_bytes(cap); }
 
 // Resident workgroups of the depth sort's scatter kernel on this device (CUs x blocks per CU).
 uint32_t gsx_sort_slots(int cus) {

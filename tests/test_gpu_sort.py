@@ -19,9 +19,15 @@ def check_contract(perm, keys_by_id, m_ids):
     assert np.all(perm[1:][same] > perm[:-1][same])
 
 
+ALGOS = [1, 2]      # gsx_set_option("sort_algo"): 1 = the three LSD radix passes, 2 = the two-pass form (partition + in-LDS bucket sort) at any size
+
+
+@pytest.mark.parametrize("algo", ALGOS)
 @pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 4095, 4096, 4097, 8192, 50000, 262144 + 17])
-def test_sort_matches_oracle(gsx, oracle, synth, n):
+def test_sort_matches_oracle(gsx_fresh, oracle, synth, n, algo):
+    gsx = gsx_fresh
     splats = oracle.raw_to_splat(synth.uniform_cloud(n, seed=n % 97 + 1))
+    gsx.set_option("sort_algo", algo)
     gsx.upload(splats)
     for cam in CAMS[:2]:
         keys = gsx.keys(cam)
@@ -35,9 +41,12 @@ def test_sort_empty_scene(gsx, oracle):
     assert len(gsx.sort(CAMS[0])) == 0
 
 
+@pytest.mark.parametrize("algo", ALGOS)
 @pytest.mark.parametrize("name", ["uniform1k", "lattice12", "clustered20k"])
-def test_sort_golden(gsx, oracle, synth, name):
+def test_sort_golden(gsx_fresh, oracle, synth, name, algo):
+    gsx = gsx_fresh
     g = golden("sort.npz")
+    gsx.set_option("sort_algo", algo)
     raw = g[f"{name}_raw"] if f"{name}_raw" in g.files else synth.clustered_cloud(20000, seed=6)
     splats = oracle.raw_to_splat(raw)
     gsx.upload(splats)
@@ -72,8 +81,11 @@ def test_sort_ties_all_equal_and_skipped_passes(gsx, oracle):
     assert gsx.timings()["sort_passes"] == 1
 
 
-def test_sort_wide_key_range(gsx, oracle):
+@pytest.mark.parametrize("algo", ALGOS)
+def test_sort_wide_key_range(gsx_fresh, oracle, algo):
+    gsx = gsx_fresh
     # distances spanning many exponents (all four radix digits vary), zeros and huge values
+    gsx.set_option("sort_algo", algo)
     rng = np.random.Generator(np.random.PCG64(5))
     n = 70000
     splats = np.zeros((n, 20), np.float32)
@@ -87,14 +99,18 @@ def test_sort_wide_key_range(gsx, oracle):
     cam = np.zeros(3, np.float32)
     assert np.array_equal(bits(gsx.keys(cam)), bits(oracle.distance_keys(splats, cam)))
     assert np.array_equal(gsx.sort(cam), oracle.sort_contract(splats, cam))
-    assert gsx.timings()["sort_passes"] == 4
+    assert gsx.timings()["sort_passes"] == (4 if algo == 1 else 3)     # (two-pass: partition + bucket sort of the low 27 bits, then the top digit)
 
 
-def test_sort_camera_inside_scene_box(gsx, oracle, synth):
+@pytest.mark.parametrize("algo", ALGOS)
+def test_sort_camera_inside_scene_box(gsx_fresh, oracle, synth, algo):
+    gsx = gsx_fresh
     """A camera inside the scene's bounding box: the host can only bound the nearest distance by 0, so the key range is
     the full 31 bits.  The low 27 bits take three passes; the top digit is a gated pass that runs only when the key
     kernel met a key that needs it (decided on the device).  Both outcomes must give the oracle's permutation."""
     n = 200_000
+    base = 3 if algo == 1 else 2                                      # passes over the low 27 bits
+    gsx.set_option("sort_algo", algo)
     splats = oracle.raw_to_splat(synth.clustered_cloud(n, seed=9))
     lo, hi = splats[:, 12:15].min(axis=0), splats[:, 12:15].max(axis=0)
     cam = (lo + (hi - lo) * np.array([0.45, 0.55, 0.5], np.float32)).astype(np.float32)
@@ -102,20 +118,59 @@ def test_sort_camera_inside_scene_box(gsx, oracle, synth):
     assert d.min() > 1e-3 * d.max()                                   # nobody close enough to need the top digit
     gsx.upload(splats)
     assert np.array_equal(gsx.sort(cam), oracle.sort_contract(splats, cam))
-    assert gsx.timings()["sort_passes"] == 3                          # gated pass queued, found nothing to do
+    assert gsx.timings()["sort_passes"] == base                       # gated pass queued, found nothing to do
     near = splats.copy()                                              # three splats at 0 .. 1e-6 from the camera
     near[[5, 77_777, n - 1], 12:15] = cam + np.array([[1e-6, 0, 0], [0, 0, 0], [0, -3e-7, 2e-7]], np.float32)
     gsx.upload(near)
     assert np.array_equal(bits(gsx.keys(cam)), bits(oracle.distance_keys(near, cam)))
     assert np.array_equal(gsx.sort(cam), oracle.sort_contract(near, cam))
-    assert gsx.timings()["sort_passes"] == 4                          # top digit executed
+    assert gsx.timings()["sort_passes"] == base + 1                   # top digit executed
     out = (hi + (hi - lo)).astype(np.float32)                         # outside the box again: the gate must be off, not stale
     assert np.array_equal(gsx.sort(out), oracle.sort_contract(near, out))
-    assert gsx.timings()["sort_passes"] == 3
+    assert gsx.timings()["sort_passes"] == base
     assert np.array_equal(gsx.sort(cam), oracle.sort_contract(near, cam))
     gsx.upload(splats)                                                # and a frame after a wide one starts from a cleared gate
     assert np.array_equal(gsx.sort(cam), oracle.sort_contract(splats, cam))
-    assert gsx.timings()["sort_passes"] == 3
+    assert gsx.timings()["sort_passes"] == base
+
+
+def test_two_pass_dense_buckets_and_ties(gsx_fresh, oracle, synth):
+    gsx = gsx_fresh
+    """The two-pass form where its buckets overflow LDS (k2_big: one workgroup per oversized bucket, LSD over (key, index)),
+    where every key of a bucket is equal (the tie rule inside one bin), and its automatic fall-back to the LSD passes."""
+    n = 400_000
+    rng = np.random.Generator(np.random.PCG64(11))
+    raw = synth.uniform_cloud(n, seed=3)
+    splats = oracle.raw_to_splat(raw)
+    # 70 % of the splats in one blob of sigma 0.004: ~50 buckets of the partition hold 5000+ keys each, many keys collide
+    k = int(0.7 * n)
+    splats[:k, 12:15] = (np.array([0.3, -0.2, 0.1]) + 0.004 * rng.standard_normal((k, 3))).astype(np.float32)
+    splats[1000:31000, 12:15] = np.float32([0.5, 0.5, -0.25])          # 30 000 splats at one point: one distance, 30 000 ties
+    gsx.upload(splats)
+    # automatic choice: the first sort takes the two-pass form, finds most keys in oversized buckets, and the following
+    # ones run the LSD passes (same permutation either way)
+    seen = []
+    for i in range(4):
+        assert np.array_equal(gsx.sort(CAMS[i % 3]), oracle.sort_contract(splats, CAMS[i % 3]))
+        seen.append(gsx.timings()["sort_passes"])
+    assert seen[0] == 2 and seen[-1] == 3, seen
+    gsx.set_option("sort_algo", 2)
+    for cam in CAMS:
+        assert np.array_equal(gsx.sort(cam), oracle.sort_contract(splats, cam))
+        assert gsx.timings()["sort_passes"] == 2
+
+
+def test_two_pass_on_a_selection_list(gsx_fresh, oracle, synth):
+    gsx = gsx_fresh
+    n = 300_000
+    splats = oracle.raw_to_splat(synth.clustered_cloud(n, seed=4))
+    gsx.set_option("sort_algo", 2)
+    gsx.upload(splats)
+    ids = np.flatnonzero(np.random.Generator(np.random.PCG64(2)).random(n) < 0.6).astype(np.uint32)
+    gsx.select_list(ids)
+    for cam in CAMS[:2]:
+        assert np.array_equal(gsx.sort(cam), oracle.sort_contract(splats, cam, ids))
+        assert gsx.timings()["sort_passes"] == 2
 
 
 def test_sort_is_repeatable_and_view_dependent(gsx, oracle, synth):
