@@ -5,9 +5,12 @@
   (N > 1: launched by torch.distributed.run, one rank per GPU)
 
 Workload (BASELINE.json configs[1]): 6M-splat synthetic clustered scene, one 1920x1080 view per step.  A *step* is
-one complete frame of the hot path on data already resident in HBM: depth keys -> stable radix sort -> projection
+one complete frame of the hot path on data already resident in HBM: depth keys -> depth sort -> projection
 -> near-to-far iterations of (occlusion-aware tile binning -> pair sort -> tile raster) into a device RGBA8
-framebuffer (no readback).
+framebuffer (no readback).  EVERY STEP RENDERS A NEW CAMERA POSE (the 120-frame orbit of SURVEY 8d, 3 degrees apart,
+starting at the default pose), so nothing a frame skips is known from an identical previous frame; the figure for a
+camera at rest (same pose every step, where the library replays per-tile saturation ranks) is reported beside it as
+`ms_per_step_static`.
 
 N > 1, two shardings over a replicated splat set:
   --shard views (default; weak scaling): a step is a batch of N views, one per rank.  Every rank renders the pose of
@@ -22,14 +25,14 @@ N > 1, two shardings over a replicated splat set:
   self-check fails.
 
 Prints ONE JSON line on rank 0.  `value` = splats sorted (and drawn) per second over whole frames, aggregated over
-ranks.  Beside the headline (one pose, history-driven schedule) the line carries `ms_per_step_no_history` (same pose,
-every iteration pre-queued) and `ms_per_step_orbit` (120-frame orbit, a new pose every step) at N = 1.
+ranks.  Beside the headline (a new pose every step) the line carries `ms_per_step_static` (one pose, history-driven
+schedule and exact rank caps) and `ms_per_step_no_history` (one pose, every iteration pre-queued, no caps) at N = 1.
 The depth sort of frame k+1 runs on a stream of its own beside the binning / rasterizing of frame k (include/gsx.h, option
-"async_sort").  `roofline` describes the radix scatter kernel (k_radix_scatter<u32>): inside the timed region every 8th
-sort is a SAMPLED one — one of its scatter launches (pass rotating), or keys + sort as a whole, is bracketed by HIP events
-on the stream it runs on, and that sort runs on the main stream, not beside the rasterizer, so that the bracket measures
-the kernel itself rather than its share of a GPU it splits with another kernel; pass 0 reads no index array and is priced
-at its real 12 B per key.  `roofline_raster`, the per-stage breakdown and the
+"async_sort").  `roofline` describes the two HBM passes of the depth sort (k2_partition and k2_local; the radix scatter
+kernel k_radix_scatter<u32> where the library runs its LSD form): inside the timed region every 4th (runs under 40 steps)
+or 8th sort is a SAMPLED one -- alternately every such launch of the sort bracketed by its own pair of HIP events, and keys
++ sort bracketed as a whole -- on the stream it runs on, and that sort runs on the main stream, not beside the rasterizer,
+so that a bracket measures the kernel itself rather than its share of a GPU it splits with another kernel.  `roofline_raster`, the per-stage breakdown and the
 rasterizer's shade / blend counts come from a few extra frames after the timed region with every stage bracketed.
 `cpu_baseline` times the CPU port of the reference's sortSplats on rank 0.
 """
@@ -52,12 +55,16 @@ SCATTER_BYTES_PASS0 = 12        # k_radix_scatter<u32, iota>: read key (4 B), wr
 SCATTER_BYTES_PASSN = 16        # passes >= 1: read key + index (8 B), write key + index (8 B)
 KEYGEN_BYTES_PER_SPLAT = 20     # float4 position read + u32 key write (pass-0 digit count fused, no extra bytes)
 COUNT_BYTES_PER_SPLAT = 4       # k_radix_hist of passes >= 1: key read
+PARTITION_BYTES = 12            # k2_partition: read key (4 B; the index is generated), write (key, index) pair (8 B)
+LOCAL_BYTES = 12                # k2_local: read pair (8 B), write index (4 B)
 BLEND_FLOP = 14                 # per pixel-splat blend: uv (5), r2 + scale (4), alpha (1), weight (1), 3 colour FMAs + T (4), 1 exp beside
 SHADE_LDS_BYTES = 48            # per (wave, splat) visit: centre/extents, uv matrix, colour records read from LDS
 
 
-def sort_bytes_per_splat(passes, iota=True):
+def sort_bytes_per_splat(passes, iota=True, form=1):
     """Algorithmic HBM bytes per splat of keys + sort."""
+    if form == 2:       # keys + counts, partition, bucket sort (the count / prefix matrices add ~3 B per splat at 6 M: not counted)
+        return KEYGEN_BYTES_PER_SPLAT + PARTITION_BYTES + LOCAL_BYTES
     if passes <= 0:
         return KEYGEN_BYTES_PER_SPLAT
     first = SCATTER_BYTES_PASS0 if iota else SCATTER_BYTES_PASSN
@@ -175,6 +182,7 @@ def main():
                     help="frames per gather at N > 1 (views); 0 = 1 for gsx_gather (the exchange stream overlaps every transfer with "
                          "the next frames anyway, and a short run then ends with one frame's transfer exposed instead of a batch's), "
                          "8 for the torch.distributed fallback (main-stream gathers)")
+    ap.add_argument("--static-view", action="store_true", help="render the SAME pose every step (a camera at rest) instead of a new orbit pose per step")
     ap.add_argument("--no-extras", action="store_true", help="skip the no-history / orbit / stage measurements after the timed region")
     ap.add_argument("--opt", action="append", default=[], help="name=value for gsx_set_option (A/B runs; not used by the driver)")
     a = ap.parse_args()
@@ -239,12 +247,18 @@ def main():
     # as a scaling loss that has nothing to do with N.  Weak scaling wants the per-GPU work fixed, so by default every rank
     # renders the pose of the N = 1 run; --distinct-views gives rank r pose r of the set instead.
     my_view = views[mg.shard_views(len(views), rank, max(world, 1))[0] if (a.distinct_views and not bands_mode) else 0]
+    # the headline walks the 120-frame orbit (3 degrees per step): every rank the same poses by default (fixed per-GPU work),
+    # --distinct-views: rank r starts 120 / N frames further along
+    path = orbit_path(pkg, 120, W, H)
+    path_unis = [pkg.make_uniforms(p[1], p[0]) for p in path]
+    pose_off = (rank * (120 // max(world, 1))) if (a.distinct_views and not bands_mode) else 0
     g = pkg.Gsx(local_rank)
     g.upload(splats)
     for o in a.opt:
         k, v = o.split("=")
         g.set_option(k, int(v))
-    g.set_profiling(2)          # sampled: in every 8th sort one k_radix_scatter launch (or the whole sort) carries HIP events
+    g.set_option("sample_every", 4 if a.steps < 40 else 8)     # (a short run still collects >= 6 launches and 2 whole sorts)
+    g.set_profiling(2)          # sampled sorts: alternately every HBM pass of the sort, and keys + sort as a whole, carry HIP events
     u_mine = pkg.make_uniforms(my_view[1], my_view[0])
     fb_bytes = W * H * 4
     bands = mg.shard_bands(H, max(world, 1))
@@ -318,10 +332,18 @@ def main():
     band_fbs = [alloc(fb_bytes)[0] for _ in range(4)] if (bands_mode and gather_kind == "gsx") else []
     band_last = [None]  # framebuffer the last exchange of the timed region gathered into
 
+    pose_no = 0
+    last_pose = [None]
+
     def step(pose=None, uniforms=None):
-        nonlocal frame_no
+        nonlocal frame_no, pose_no
+        if pose is None and not a.static_view:
+            k = (pose_no + pose_off) % len(path)
+            pose, uniforms = path[k][2], path_unis[k]
+            pose_no += 1
         pos = my_view[2] if pose is None else pose
         uni = u_mine if uniforms is None else uniforms
+        last_pose[0] = (pos, uni)
         g.sort(pos, download=False)          # queued behind the running frame
         if bands_mode:
             if exchange and gather_kind == "gsx":
@@ -430,8 +452,8 @@ def main():
             gathered = mg.compose_bands(band_recv, bands, W).cpu().numpy()
         else:
             hip.hipMemcpy(C.c_void_p(gathered.ctypes.data), C.c_void_p(band_last[0] or g.framebuffer_dev()[0]), C.c_size_t(fb_bytes), C.c_int(2))
-        g.sort(my_view[2], download=False)
-        alone = g.render(u_mine, W, H).reshape(-1)
+        g.sort(last_pose[0][0], download=False)
+        alone = g.render(last_pose[0][1], W, H).reshape(-1)
         bands_match = bool(np.array_equal(gathered, alone)) if (world == 1 or gather_kind != "none") else None
     fg = bg = None                                       # everything below is rank 0's alone: no collective
     exchange = False
@@ -443,27 +465,26 @@ def main():
         g.set_framebuffer_dev(None)
         if world == 1 and not bands_mode:
             K2 = max(10, min(a.steps, 40))
-            g.set_option("no_history", 1)
             for i in range(3):
-                step()
+                step(my_view[2], u_mine)
             g.sync()
             t1 = time.perf_counter()
             for i in range(K2):
-                step()
+                step(my_view[2], u_mine)
+            g.sync()
+            extras["ms_per_step_static"] = (time.perf_counter() - t1) / K2 * 1e3
+            extras["static_note"] = ("the SAME pose every step: the history-driven schedule is perfectly predicted and every tile is binned only up to the "
+                                     "rank at which it saturated in the identical previous frame (not the headline: that replays knowledge of the answer)")
+            g.set_option("no_history", 1)
+            for i in range(3):
+                step(my_view[2], u_mine)
+            g.sync()
+            t1 = time.perf_counter()
+            for i in range(K2):
+                step(my_view[2], u_mine)
             g.sync()
             extras["ms_per_step_no_history"] = (time.perf_counter() - t1) / K2 * 1e3
             g.set_option("no_history", 0)
-            path = orbit_path(pkg, 120, W, H)
-            unis = [pkg.make_uniforms(p[1], p[0]) for p in path]
-            for i in range(4):
-                step(path[i][2], unis[i])
-            g.sync()
-            t1 = time.perf_counter()
-            for i in range(120):
-                step(path[i][2], unis[i])
-            g.sync()
-            extras["ms_per_step_orbit"] = (time.perf_counter() - t1) / 120 * 1e3
-            extras["orbit_note"] = "120-frame orbit about +Y (2 pi / 120 per frame), a new pose every step, default history-driven schedule"
         # stage breakdown on a few extra frames with every stage bracketed (outside the timed region)
         g.set_profiling(1)
         for i in range(n_prof + 1):
@@ -477,21 +498,26 @@ def main():
         K, n = a.steps, a.splats
         frames_total = K * (1 if bands_mode else world)
         n_pass = int(round(passes))
-        # the roofline kernel: every sampled launch priced at its own bytes (pass 0 generates the index: 12 B per key)
-        launch_bytes = {p: (SCATTER_BYTES_PASS0 if p == 0 else SCATTER_BYTES_PASSN) * n for p in per_pass}
+        form = int(t.get("sort_form", 1))
+        # the roofline kernels: every sampled launch priced at its own bytes
+        if form == 2:
+            stage_bytes = {0: PARTITION_BYTES, 1: LOCAL_BYTES}
+            launch_bytes = {p: stage_bytes.get(p, LOCAL_BYTES) * n for p in per_pass}
+        else:   # (pass 0 of the radix form generates the index: 12 B per key)
+            launch_bytes = {p: (SCATTER_BYTES_PASS0 if p == 0 else SCATTER_BYTES_PASSN) * n for p in per_pass}
         sum_ms = sum(per_pass[p] * pass_n[p] for p in per_pass)
         sum_bytes = sum(launch_bytes[p] * pass_n[p] for p in per_pass)
         launches = sum(pass_n.values())
         launch_ms = sum_ms / launches if launches else 0.0
         achieved = sum_bytes / (sum_ms * 1e-3) / 1e9 if sum_ms > 0 else 0.0
-        sort_bytes = sort_bytes_per_splat(n_pass)
+        sort_bytes = sort_bytes_per_splat(n_pass, form=form)
         traffic, traffic_src = None, None
-        tf = os.path.join(ROOT, "profiles", "r2_scatter_traffic.json")     # PMC passes (tools/pmc_traffic.sh), committed
+        tf = os.path.join(ROOT, "profiles", "r3_sort_traffic.json" if form == 2 else "r2_scatter_traffic.json")     # PMC passes (tools/pmc_traffic.sh), committed
         if os.path.exists(tf):
             rec = json.load(open(tf))
             if rec.get("splats") == n:
                 traffic = rec.get("hbm_bytes_per_launch")
-                traffic_src = "profiles/r2_scatter_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (tools/pmc_traffic.sh), not measured in this run"
+                traffic_src = f"profiles/{os.path.basename(tf)}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (tools/pmc_traffic.sh), not measured in this run"
         out = {
             "metric": f"splats_sorted_per_s (whole {W}x{H} frame: keys+sort+project+bin+raster)",
             "value": n * frames_total / elapsed,
@@ -506,9 +532,11 @@ def main():
             "dtype": "f32 keys / u32 radix",
             "data": "synthetic",
             "config": {"workload": (f"cfg5: {n}-splat overlap-stress scene, ONE {W}x{H} frame per step in {world} tile band(s)" if bands_mode else
-                                    f"cfg2: {n}-splat clustered synthetic scene, single view {W}x{H} per step"),
+                                    f"cfg2: {n}-splat clustered synthetic scene, single view {W}x{H} per step" +
+                                    (", the same pose every step" if a.static_view else ", a new camera pose every step (120-frame orbit, 3 degrees apart)")),
                        "splats": n, "width": W, "height": H, "views_per_step_per_gpu": None if bands_mode else 1,
-                       "poses": "one pose" if bands_mode else ("rank r renders pose r" if a.distinct_views else "every rank renders the N=1 pose (fixed per-GPU work)"),
+                       "poses": ("one pose" if a.static_view else "120-frame orbit, one new pose per step") +
+                                ("" if bands_mode else ("; rank r starts 120/N frames further along" if a.distinct_views else "; every rank renders the N=1 poses (fixed per-GPU work)")),
                        "sharding": ("screen-space tile bands over replicated splats" if bands_mode else "camera views over replicated splats"),
                        "gather": {"gsx": f"gsx_gather (grouped RCCL send/recv on the library's exchange stream)" + ("" if bands_mode else f", batches of {a.gather_batch} frames"),
                                   "torch": "torch.distributed.gather (nccl = RCCL)", "none": "none"}[gather_kind]},
@@ -517,15 +545,18 @@ def main():
             "render_iters": iters,
             "sort_passes": n_pass,
             "async_sort": not any(o.startswith("async_sort=0") for o in a.opt),
-            "roofline": {"kernel": "k_radix_scatter<u32> (one stable radix scatter pass of the depth sort)", "bound": "hbm", "achieved": achieved,
+            "sort_form": "two-pass (keys + top-digit counts, column scan, partition, in-LDS bucket sort)" if form == 2 else "LSD radix passes",
+            "roofline": {"kernel": ("k2_partition + k2_local (the two HBM passes of the depth sort behind the key kernel)" if form == 2 else
+                                    "k_radix_scatter<u32> (one stable radix scatter pass of the depth sort)"), "bound": "hbm", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "avg_launch_ms": launch_ms, "per_pass_launch_ms": [per_pass[p] for p in sorted(per_pass)],
                          "per_pass_bytes": [launch_bytes[p] for p in sorted(per_pass)],
                          "launches_per_step": n_pass, "launches_timed": int(launches),
                          "algorithmic_bytes_per_launch": sum_bytes / launches if launches else None,
-                         "note": "HIP events inside the timed region around one scatter launch of every 8th sort (pass rotating); the sampled sorts run on the main stream, "
-                                 "un-overlapped (the other 7 of 8 sorts run beside the previous frame's rasterizer, where the same launch takes ~2.4x as long: DESIGN.md 4.6); "
-                                 "pass 0 priced at 12 B/key, passes >= 1 at 16 B/key"},
+                         "note": "HIP events inside the timed region: every other sampled sort (one sort in 4 or 8 is sampled) brackets each of these launches; the sampled sorts run "
+                                 "on the main stream, un-overlapped (the others run beside the previous frame's rasterizer, where the same launch takes about twice as long: "
+                                 "DESIGN.md 4.6); " + ("partition: 4 B key in + 8 B pair out, bucket sort (its two size classes + the gated overflow kernel as one bracket): 8 B in + 4 B out"
+                                                       if form == 2 else "pass 0 priced at 12 B/key, passes >= 1 at 16 B/key")},
         }
         if not bands_mode:
             out["fps_1080p"] = out["fps"]
@@ -539,7 +570,7 @@ def main():
         if sort_n_timed:
             out["sort_only_ms"] = sort_ms_timed
             out["sort_only_samples"] = sort_n_timed
-            out["sort_only_note"] = "keys + sort bracketed as a whole by HIP events in every 32nd frame INSIDE the timed region (a sampled sort: on the main stream, not overlapped)"
+            out["sort_only_note"] = "keys + sort bracketed as a whole by HIP events in every other sampled sort INSIDE the timed region (a sampled sort: on the main stream, not overlapped)"
             out["sort_only_splats_per_s"] = n / (sort_ms_timed * 1e-3)
             out["sort_only_bytes_per_splat"] = sort_bytes
             out["sort_only_hbm_frac"] = sort_bytes * n / (sort_ms_timed * 1e-3) / 1e9 / HBM_PEAK_GBS

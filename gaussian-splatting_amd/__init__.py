@@ -53,7 +53,8 @@ class Timings(C.Structure):
     _fields_ = [("select_ms", C.c_float), ("keygen_ms", C.c_float), ("sort_ms", C.c_float), ("scatter_ms", C.c_float), ("project_ms", C.c_float),
                 ("bin_ms", C.c_float), ("raster_ms", C.c_float), ("total_ms", C.c_float), ("sort_passes", C.c_uint32),
                 ("sort_launches", C.c_uint32), ("tile_pairs", C.c_uint64), ("render_iters", C.c_uint32), ("scatter_sample", C.c_uint32),
-                ("raster_shades", C.c_uint64), ("raster_blends", C.c_uint64), ("raster_staged", C.c_uint64), ("render_capped", C.c_uint32), ("render_redos", C.c_uint32)]
+                ("raster_shades", C.c_uint64), ("raster_blends", C.c_uint64), ("raster_staged", C.c_uint64), ("render_capped", C.c_uint32), ("render_redos", C.c_uint32),
+                ("sort_form", C.c_uint32), ("reserved0", C.c_uint32)]
 
 
 assert C.sizeof(Uniforms) == 224

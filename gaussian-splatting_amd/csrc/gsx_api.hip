@@ -341,6 +341,7 @@ int gsx_get_timings(gsx_ctx* c, gsx_timings* out) {
     if (c->sorted_valid) {
         t.sort_passes = c->sort_passes;
         t.sort_launches = c->sort_launches;
+        t.sort_form = c->sort_two_pass ? 2u : 1u;
         if (c->sort_gated) {                        // the gated top-digit pass: launched (+ its copy), executed only if a key needed it
             uint32_t wide = 0;
             GSX_HIP(c, hipMemcpy(&wide, &c->flags->wide_m, sizeof wide, hipMemcpyDeviceToHost));

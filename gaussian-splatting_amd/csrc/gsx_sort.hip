@@ -248,7 +248,6 @@ static int launch_sort_in(gsx_ctx* c, const GsxSortBuffers& sb, hipStream_t st) 
     const uint32_t top_bits = total_bits > LOW_BITS ? total_bits - LOW_BITS : 0u;
     const GsxRadixPlan plan = gsx_radix_plan(top_bits ? LOW_BITS : total_bits);
     const uint32_t wide_mask = top_bits ? ~((1u << LOW_BITS) - 1u) : 0u;
-    if (top_bits) GSX_HIP(c, hipMemsetAsync(&c->flags->wide_m, 0, sizeof(uint32_t), st));
     // The two-pass form (gsx_sort2.hpp: one wide partition + one kernel that finishes every bucket in LDS) when its plan
     // allows; the LSD passes below otherwise (small sorts, narrow key ranges, gsx_sort_noalloc) and for a while after a
     // sort whose buckets were too dense for LDS (history, checked without waiting).
@@ -264,74 +263,71 @@ static int launch_sort_in(gsx_ctx* c, const GsxSortBuffers& sb, hipStream_t st) 
                 c->s2_backoff_len = 0;
             }
         }
-        p2 = gsx2_plan(top_bits ? (1u << LOW_BITS) - 1u : key_span, cap, c->n, 0, c->opt_sort_algo == 2);
+        p2 = gsx2_plan(key_span, cap, c->n, 0, c->opt_sort_algo == 2);
         if (p2.ok && c->opt_sort_algo == 0 && c->s2_backoff) { --c->s2_backoff; p2.ok = false; }
     }
+    const bool gated = top_bits != 0 && !p2.ok;      // (the two-pass form orders all 31 key bits itself: its buckets widen towards the camera)
+    if (gated) GSX_HIP(c, hipMemsetAsync(&c->flags->wide_m, 0, sizeof(uint32_t), st));
     const int n_stage = p2.ok ? 2 : plan.n_passes;    // launches a level-2 sample can bracket: radix passes, or partition + bucket sort
-    // Profiling level 2 brackets ONE thing in every opt_sample_every-th sort with a pair of events from the ring, rotating:
-    // the scatter launch of pass 0, 1, ..., and (slot GSX_SAMPLE_WHOLE) the whole of keys + sort, from before the key kernel
-    // to behind the last pass.  A sampled sort runs on the main stream (gsx_launch_sort), i.e. NOT beside the previous
-    // frame's rasterizer, so that the bracket measures the kernel and not its share of a GPU it has to split.
+    // Profiling level 2: every opt_sample_every-th sort is a SAMPLED one, alternately (a) every scatter launch of the radix
+    // passes -- or the partition and the bucket-sort launches of the two-pass form -- each bracketed by its own pair of events
+    // from the ring, and (b) keys + sort as a whole (slot GSX_SAMPLE_WHOLE), from before the key kernel to behind the last
+    // pass.  A sampled sort runs on the main stream (gsx_launch_sort), i.e. NOT beside the previous frame's rasterizer, so
+    // that a bracket measures the kernel and not its share of a GPU it has to split.
+    hipEvent_t samp_a[GSX_SAMPLE_WHOLE + 1] = {}, samp_b[GSX_SAMPLE_WHOLE + 1] = {};
+    auto take_slot = [&](int what) {
+        const uint32_t slot = c->samp_pos++ % GSX_SAMPLE_RING;
+        gsx_sample_drain(c, slot);                  // (a slot comes round again 32 samples later: long finished)
+        c->samp_pass[slot] = what;
+        samp_a[what] = c->samp_ev[slot][0];
+        samp_b[what] = c->samp_ev[slot][1];
+    };
     int sampled_pass = -1;
     if (sb.with_events) {
         if (c->prof_level == 2 && n_stage > 0 && c->prof_frame % c->opt_sample_every == 0u) {
-            const uint32_t turn = (c->prof_frame / c->opt_sample_every) % (static_cast<uint32_t>(n_stage) + 1u);
-            sampled_pass = turn == static_cast<uint32_t>(n_stage) ? GSX_SAMPLE_WHOLE : static_cast<int>(turn);
+            if ((c->prof_frame / c->opt_sample_every) % 2u == 1u) {
+                sampled_pass = GSX_SAMPLE_WHOLE;
+                take_slot(GSX_SAMPLE_WHOLE);
+            } else {
+                sampled_pass = 0;
+                for (int p = 0; p < n_stage && p < GSX_SAMPLE_WHOLE; ++p) take_slot(p);
+            }
         }
         c->sampled_pass = sampled_pass;
         ++c->prof_frame;
     }
-    hipEvent_t samp0 = nullptr, samp1 = nullptr;
-    if (sampled_pass >= 0) {
-        const uint32_t slot = c->samp_pos++ % GSX_SAMPLE_RING;
-        gsx_sample_drain(c, slot);                  // (a slot comes round again 32 frames later: long finished)
-        c->samp_pass[slot] = sampled_pass;
-        samp0 = c->samp_ev[slot][0];
-        samp1 = c->samp_ev[slot][1];
-    }
-    if (sampled_pass == GSX_SAMPLE_WHOLE) GSX_HIP(c, hipEventRecord(samp0, st));
+    if (sampled_pass == GSX_SAMPLE_WHOLE) GSX_HIP(c, hipEventRecord(samp_a[GSX_SAMPLE_WHOLE], st));
     if (profiling) GSX_HIP(c, hipEventRecord(c->ev[EV_KEY0], st));
     uint32_t cur = 0;
     uint32_t* result = sb.result;
     if (p2.ok) {
         const Gsx2Workspace w = gsx2_ws_carve(c->s2_ws, c->sort_cap);
-        uint32_t* keys_out = top_bits ? sb.keys[1] : nullptr;     // the gated pass wants the sorted keys beside the permutation
         if (c->sel_iota)
             hipLaunchKernelGGL(k2_keygen_hist<true>, dim3(p2.ncols), dim3(GSX2_NT), 0, st, c->pos4, nullptr, c->m_dev, c->cam[0], c->cam[1],
-                               c->cam[2], key_lo, key_span, p2.low_mask, p2.r, p2.nd, wide_mask, sb.keys[0], w.cnt, c->flags, sb.m_copy, w.stats);
+                               c->cam[2], key_lo, key_span, p2.map, p2.nd, sb.keys[0], w.cnt, c->flags, sb.m_copy, w.stats);
         else
             hipLaunchKernelGGL(k2_keygen_hist<false>, dim3(p2.ncols), dim3(GSX2_NT), 0, st, c->pos4, c->sel_idx, c->m_dev, c->cam[0], c->cam[1],
-                               c->cam[2], key_lo, key_span, p2.low_mask, p2.r, p2.nd, wide_mask, sb.keys[0], w.cnt, c->flags, sb.m_copy, w.stats);
+                               c->cam[2], key_lo, key_span, p2.map, p2.nd, sb.keys[0], w.cnt, c->flags, sb.m_copy, w.stats);
         if (profiling) GSX_HIP(c, hipEventRecord(c->ev[EV_KEY1], st));
         hipLaunchKernelGGL(k2_scan, dim3(p2.nd / 16), dim3(512), 0, st, w.cnt, w.pre, w.totals, p2.nd, p2.ncols);
-        hipEvent_t e0 = profiling ? c->ev[EV_X0] : (sampled_pass == 0 ? samp0 : nullptr);
-        hipEvent_t e1 = profiling ? c->ev[EV_X0 + 1] : (sampled_pass == 0 ? samp1 : nullptr);
+        hipEvent_t e0 = profiling ? c->ev[EV_X0] : samp_a[0];
+        hipEvent_t e1 = profiling ? c->ev[EV_X0 + 1] : samp_b[0];
         if (e0) GSX_HIP(c, hipEventRecord(e0, st));
         if (c->sel_iota)
-            hipLaunchKernelGGL(k2_partition<true>, dim3(p2.ncols), dim3(GSX2_PNT), 0, st, sb.keys[0], nullptr, c->m_dev, p2.low_mask, p2.r, p2.nd,
+            hipLaunchKernelGGL(k2_partition<true>, dim3(p2.ncols), dim3(GSX2_PNT), 0, st, sb.keys[0], nullptr, c->m_dev, p2.map, p2.nd,
                                w.cnt, w.pre, w.totals, w.base, c->s2_pairs, w.stats, c->flags);
         else
-            hipLaunchKernelGGL(k2_partition<false>, dim3(p2.ncols), dim3(GSX2_PNT), 0, st, sb.keys[0], c->sel_idx, c->m_dev, p2.low_mask, p2.r,
+            hipLaunchKernelGGL(k2_partition<false>, dim3(p2.ncols), dim3(GSX2_PNT), 0, st, sb.keys[0], c->sel_idx, c->m_dev, p2.map,
                                p2.nd, w.cnt, w.pre, w.totals, w.base, c->s2_pairs, w.stats, c->flags);
         if (e1) GSX_HIP(c, hipEventRecord(e1, st));
-        e0 = profiling ? c->ev[EV_X0 + 2] : (sampled_pass == 1 ? samp0 : nullptr);
-        e1 = profiling ? c->ev[EV_X0 + 3] : (sampled_pass == 1 ? samp1 : nullptr);
+        e0 = profiling ? c->ev[EV_X0 + 2] : samp_a[1];
+        e1 = profiling ? c->ev[EV_X0 + 3] : samp_b[1];
         if (e0) GSX_HIP(c, hipEventRecord(e0, st));
-        if (top_bits) {
-            hipLaunchKernelGGL((k2_local<GSX2_IPT, true>), dim3(p2.nd), dim3(GSX2_NT), 0, st, c->s2_pairs, w.base, p2.nd, p2.r, p2.q_min, p2.q, p2.idx_bits,
-                               result, keys_out, w.big_list, w.stats, c->flags);
-            hipLaunchKernelGGL((k2_local<8, true>), dim3(p2.nd), dim3(GSX2_NT), 0, st, c->s2_pairs, w.base, p2.nd, p2.r, p2.q_min, p2.q, p2.idx_bits, result,
-                               keys_out, w.big_list, w.stats, c->flags);
-            hipLaunchKernelGGL(k2_big<true>, dim3(256), dim3(GSX2_NT), 0, st, c->s2_pairs, c->s2_scratch, w.base, p2.r, p2.idx_bits, result, keys_out,
-                               w.big_list, w.stats);
-        } else {
-            hipLaunchKernelGGL((k2_local<GSX2_IPT, false>), dim3(p2.nd), dim3(GSX2_NT), 0, st, c->s2_pairs, w.base, p2.nd, p2.r, p2.q_min, p2.q, p2.idx_bits,
-                               result, keys_out, w.big_list, w.stats, c->flags);
-            hipLaunchKernelGGL((k2_local<8, false>), dim3(p2.nd), dim3(GSX2_NT), 0, st, c->s2_pairs, w.base, p2.nd, p2.r, p2.q_min, p2.q, p2.idx_bits, result,
-                               keys_out, w.big_list, w.stats, c->flags);
-            hipLaunchKernelGGL(k2_big<false>, dim3(256), dim3(GSX2_NT), 0, st, c->s2_pairs, c->s2_scratch, w.base, p2.r, p2.idx_bits, result, keys_out,
-                               w.big_list, w.stats);
-        }
+        hipLaunchKernelGGL((k2_local<GSX2_IPT>), dim3(p2.nd), dim3(GSX2_NT), 0, st, c->s2_pairs, w.base, p2.nd, p2.map, p2.idx_bits, result, w.big_list,
+                           w.stats, c->flags);
+        hipLaunchKernelGGL((k2_local<8>), dim3(p2.nd), dim3(GSX2_NT), 0, st, c->s2_pairs, w.base, p2.nd, p2.map, p2.idx_bits, result, w.big_list, w.stats,
+                           c->flags);
+        hipLaunchKernelGGL(k2_big, dim3(256), dim3(GSX2_NT), 0, st, c->s2_pairs, c->s2_scratch, w.base, p2.map, p2.idx_bits, result, w.big_list, w.stats);
         if (e1) GSX_HIP(c, hipEventRecord(e1, st));
         // bucket statistics for the next sorts' choice of form (read when the copy has landed, never waited for)
         if (!c->s2_stats_rec) {
@@ -339,7 +335,6 @@ static int launch_sort_in(gsx_ctx* c, const GsxSortBuffers& sb, hipStream_t st) 
             GSX_HIP(c, hipEventRecord(c->ev_s2_stats, st));
             c->s2_stats_rec = true;
         }
-        cur = 1;      // (the gated pass reads keys[1] + the permutation)
     } else {
     if (c->sel_iota)
         hipLaunchKernelGGL(k_keygen_hist0<true>, dim3(g), dim3(GSX_SORT_NT), 0, st, c->pos4, nullptr, c->m_dev, c->cam[0],
@@ -352,15 +347,15 @@ static int launch_sort_in(gsx_ctx* c, const GsxSortBuffers& sb, hipStream_t st) 
     if (profiling) GSX_HIP(c, hipEventRecord(c->ev[EV_KEY1], st));
     for (int p = 0; p < plan.n_passes; ++p) {
         const bool first = p == 0, last = p + 1 == plan.n_passes;
-        hipEvent_t e0 = profiling ? c->ev[EV_X0 + 2 * p] : (sampled_pass == p ? samp0 : nullptr);
-        hipEvent_t e1 = profiling ? c->ev[EV_X0 + 2 * p + 1] : (sampled_pass == p ? samp1 : nullptr);
+        hipEvent_t e0 = profiling ? c->ev[EV_X0 + 2 * p] : samp_a[p];
+        hipEvent_t e1 = profiling ? c->ev[EV_X0 + 2 * p + 1] : samp_b[p];
         launch_pass<uint32_t, GSX_SORT_NT, GSX_SORT_IPT>(c, st, g, sb.keys[cur], first ? c->sel_idx : sb.vals[cur], sb.keys[cur ^ 1],
                                                           last ? result : sb.vals[cur ^ 1], c->m_dev, plan.shift[p], plan.bits[p], sb.ws,
                                                           cols, /*need_hist=*/!first, /*iota=*/first && c->sel_iota, e0, e1);
         cur ^= 1;
     }
     }
-    if (top_bits) {   // gated top digit: result -> scratch values, then back (all four kernels see count 0 in the common case)
+    if (gated) {   // gated top digit: result -> scratch values, then back (all four kernels see count 0 in the common case)
         static_assert(EV_X0 + 2 * 3 + 1 < EV_X_END, "event slots of the gated pass");
         launch_pass<uint32_t, GSX_SORT_NT, GSX_SORT_IPT>(c, st, g, sb.keys[cur], result, sb.keys[cur ^ 1], sb.vals[cur ^ 1],
                                                           &c->flags->wide_m, LOW_BITS, top_bits, sb.ws, cols, /*need_hist=*/true,
@@ -368,12 +363,12 @@ static int launch_sort_in(gsx_ctx* c, const GsxSortBuffers& sb, hipStream_t st) 
                                                           profiling ? c->ev[EV_X0 + 7] : nullptr);
         hipLaunchKernelGGL(k_copy_gated, dim3(g), dim3(512), 0, st, &c->flags->wide_m, sb.vals[cur ^ 1], result);
     }
-    if (sampled_pass == GSX_SAMPLE_WHOLE) GSX_HIP(c, hipEventRecord(samp1, st));
+    if (sampled_pass == GSX_SAMPLE_WHOLE) GSX_HIP(c, hipEventRecord(samp_b[GSX_SAMPLE_WHOLE], st));
     if (profiling) GSX_HIP(c, hipEventRecord(c->ev[EV_SORT1], st));
     GSX_HIP(c, hipGetLastError());
     if (sb.with_events) {   // (the context's own sort: what gsx_get_timings reports)
-        c->sort_passes = static_cast<uint32_t>(n_stage) + (top_bits ? 1u : 0u);   // (the gated pass counts as launched)
-        c->sort_gated = top_bits != 0;
+        c->sort_passes = static_cast<uint32_t>(n_stage) + (gated ? 1u : 0u);   // (the gated pass counts as launched)
+        c->sort_gated = gated;
         c->sort_two_pass = p2.ok;
         c->sort_launches = p2.ok ? 6u : 3u * static_cast<uint32_t>(plan.n_passes) - 1u;   // (pass 0's count is fused into the key kernel)
     }

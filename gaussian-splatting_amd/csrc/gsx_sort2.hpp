@@ -45,12 +45,42 @@ struct Gsx2Stats {
     uint32_t big_count;      // list length (k2_local appends, k2_big consumes; zeroed by k2_keygen_hist)
 };
 
+// Bucket of a (relative) key.  Keys are inverted float bit patterns, so 2^23 consecutive key values span a factor of two in
+// distance.  The far 2^25 key values (where nearly all splats of a scene lie) are cut into buckets of 2^r0 values; behind
+// them every further window of 2^23 values (distance halves, the splat count drops ~8 x) gets half as many buckets as the one
+// before, down to one bucket per window.  With a camera inside the scene's bounding box the host can bound the nearest
+// distance only by 0 and the key range is the full 31 bits: the ~5 K buckets still sit where the splats are.
+struct Gsx2Map {
+    uint32_t r0;      // low key bits inside a bucket of the fine region
+    uint32_t nf;      // 23 - r0: log2 of the fine buckets per window
+    uint32_t base;    // buckets of the fine region: 2^25 >> r0
+};
+__host__ __device__ __forceinline__ uint32_t gsx2_bucket(uint32_t rel, const Gsx2Map mp) {
+    if (rel < (1u << 25)) return rel >> mp.r0;
+    const uint32_t e = (rel - (1u << 25)) >> 23;
+    if (e < mp.nf) return mp.base + (1u << mp.nf) - (1u << (mp.nf - e)) + ((rel & 0x7FFFFFu) >> (mp.r0 + 1u + e));
+    return mp.base + (1u << mp.nf) - 1u + (e - mp.nf);
+}
+// low key bits that vary inside bucket d
+__host__ __device__ __forceinline__ uint32_t gsx2_bucket_bits(uint32_t d, const Gsx2Map mp) {
+    if (d < mp.base) return mp.r0;
+    const uint32_t x = d - mp.base;
+    if (x + 1u >= (1u << mp.nf)) return 23u;
+    const uint32_t y = (1u << mp.nf) - 1u - x;                       // >= 1
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t lg = 31u - static_cast<uint32_t>(__clz(static_cast<int>(y)));
+#else
+    const uint32_t lg = 31u - static_cast<uint32_t>(__builtin_clz(y));
+#endif
+    return mp.r0 + 1u + (mp.nf - 1u - lg);
+}
+
 // ---- A: keys + per-column counts of the top digit ------------------------------------------------------------
 // cnt[col * nd + d], 2-byte counts (a column holds at most GSX2_COLMAX keys).  Grid = number of columns.
 template <bool IOTA>
 __global__ __launch_bounds__(GSX2_NT) void k2_keygen_hist(const float4* __restrict__ pos4, const uint32_t* __restrict__ sel,
                                                           const uint32_t* __restrict__ m_ptr, float cx, float cy, float cz, uint32_t key_lo,
-                                                          uint32_t key_span, uint32_t low_mask, uint32_t r, uint32_t nd, uint32_t wide_mask,
+                                                          uint32_t key_span, Gsx2Map mp, uint32_t nd,
                                                           uint32_t* __restrict__ keys, uint16_t* __restrict__ cnt, GsxDevFlags* __restrict__ flags,
                                                           uint32_t* __restrict__ m_copy, Gsx2Stats* __restrict__ stats) {
     __shared__ uint32_t s_hist[GSX2_MAX_D];
@@ -62,7 +92,7 @@ __global__ __launch_bounds__(GSX2_NT) void k2_keygen_hist(const float4* __restri
     for (uint32_t t = threadIdx.x; t < nd; t += GSX2_NT) s_hist[t] = 0;
     __syncthreads();
     const uint32_t col = gsx_logical_block();
-    uint32_t begin, end, top = 0;
+    uint32_t begin, end;
     gsx_block_range(m, gridDim.x, col, begin, end);
     constexpr int UNROLL = 4;
     for (uint32_t base = begin + threadIdx.x; base < end; base += GSX2_NT * UNROLL) {
@@ -85,15 +115,13 @@ __global__ __launch_bounds__(GSX2_NT) void k2_keygen_hist(const float4* __restri
                 rel = (key < key_lo) ? 0u : key_span;
             }
             keys[k] = rel;
-            top |= rel & wide_mask;
-            atomicAdd(&s_hist[(rel & low_mask) >> r], 1u);
+            atomicAdd(&s_hist[gsx2_bucket(rel, mp)], 1u);
         }
     }
     __syncthreads();
     // two 2-byte counts per lane: a wave writes 256 contiguous bytes (nd is a multiple of 128)
     uint32_t* out = reinterpret_cast<uint32_t*>(cnt + static_cast<uint64_t>(col) * nd);
     for (uint32_t t = threadIdx.x; t < nd / 2; t += GSX2_NT) out[t] = s_hist[2 * t] | (s_hist[2 * t + 1] << 16);
-    if (top != 0u) atomicMax(&flags->wide_m, m);
 }
 
 // ---- B: per bucket, exclusive prefix over the columns -----------------------------------------------------------
@@ -146,7 +174,7 @@ __global__ __launch_bounds__(512) void k2_scan(const uint16_t* __restrict__ cnt,
 // straight from its thread (6 M isolated 8-byte stores) took 74 us at 6 M keys, bound by requests, not bytes.
 template <bool IOTA>
 __global__ __launch_bounds__(GSX2_PNT) void k2_partition(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ sel,
-                                                         const uint32_t* __restrict__ m_ptr, uint32_t low_mask, uint32_t r, uint32_t nd,
+                                                         const uint32_t* __restrict__ m_ptr, Gsx2Map mp, uint32_t nd,
                                                          const uint16_t* __restrict__ cnt, const uint32_t* __restrict__ pre,
                                                          const uint32_t* __restrict__ totals, uint32_t* __restrict__ base_out,
                                                          uint2* __restrict__ pairs, Gsx2Stats* __restrict__ stats, GsxDevFlags* __restrict__ flags) {
@@ -225,7 +253,7 @@ __global__ __launch_bounds__(GSX2_PNT) void k2_partition(const uint32_t* __restr
     for (int j = 0; j < GSX2_KPT; ++j) {
         const uint32_t k = begin + j * GSX2_PNT + tid;
         if (k < end) {
-            const uint32_t d = (key[j] & low_mask) >> r;
+            const uint32_t d = gsx2_bucket(key[j], mp);
             const uint32_t sh = (d & 1u) * 16u;
             const uint32_t old = atomicAdd(&s_cur[d >> 1], 1u << sh);
             const uint32_t slot = (old >> sh) & 0xFFFFu;
@@ -235,7 +263,7 @@ __global__ __launch_bounds__(GSX2_PNT) void k2_partition(const uint32_t* __restr
     __syncthreads();
     for (uint32_t p = tid; p < csize; p += GSX2_PNT) {
         const uint2 pr = s_pair[p];
-        const uint32_t dst = s_adj[(pr.x & low_mask) >> r] + p;
+        const uint32_t dst = s_adj[gsx2_bucket(pr.x, mp)] + p;
         if (dst < m) pairs[dst] = pr;   // (always true for a consistent count matrix)
     }
 }
@@ -244,10 +272,10 @@ __global__ __launch_bounds__(GSX2_PNT) void k2_partition(const uint32_t* __restr
 // Element word in LDS: (key bits below the bin << idx_bits) | index  (the host checks that this fits 32 bits).
 // Two instances share the buckets by size: IPT = 8 (up to 4096 pairs, 24 KB of LDS: four workgroups per CU) takes the
 // many ordinary buckets, IPT = GSX2_IPT (up to GSX2_CAP) the few large ones and lists what exceeds even that for k2_big.
-template <int IPT, bool WIDE>
+template <int IPT>
 __global__ __launch_bounds__(GSX2_NT) void k2_local(const uint2* __restrict__ pairs, const uint32_t* __restrict__ base, uint32_t nd,
-                                                    uint32_t r, uint32_t q_min, uint32_t q_max, uint32_t idx_bits, uint32_t* __restrict__ result,
-                                                    uint32_t* __restrict__ keys_out, uint32_t* __restrict__ big_list,
+                                                    Gsx2Map mp, uint32_t idx_bits, uint32_t* __restrict__ result,
+                                                    uint32_t* __restrict__ big_list,
                                                     Gsx2Stats* __restrict__ stats, GsxDevFlags* __restrict__ flags) {
     constexpr bool LARGE = IPT > 8;
     constexpr int QMAX = LARGE ? GSX2_MAX_Q : 12;
@@ -259,9 +287,13 @@ __global__ __launch_bounds__(GSX2_NT) void k2_local(const uint2* __restrict__ pa
     const uint32_t b0 = base[d], size = base[d + 1] - b0;
     if (size == 0) return;
     if (LARGE ? size <= 8u * GSX2_NT : size > 8u * GSX2_NT) return;      // the other instance's bucket
-    const uint32_t rmask = r >= 32 ? 0xFFFFFFFFu : ((1u << r) - 1u);
+    const uint32_t r = gsx2_bucket_bits(d, mp);
+    const uint32_t rmask = (1u << r) - 1u;
     const uint32_t idx_mask = idx_bits >= 32 ? 0xFFFFFFFFu : ((1u << idx_bits) - 1u);
-    if (size > GSX2_CAP) {
+    // bins: at most 2^QMAX and never finer than a key value; the key bits below the bin share a word with the index
+    const uint32_t q_max = r < static_cast<uint32_t>(QMAX) ? r : static_cast<uint32_t>(QMAX);
+    const uint32_t q_min = r + idx_bits > 32u ? r + idx_bits - 32u : 0u;
+    if (size > GSX2_CAP || (size > 64u && q_min > q_max)) {
         if (tid == 0) {
             const uint32_t slot = atomicAdd(&stats->big_count, 1u);
             if (slot < GSX2_BIG_LIST) big_list[slot] = d;
@@ -281,15 +313,13 @@ __global__ __launch_bounds__(GSX2_NT) void k2_local(const uint2* __restrict__ pa
         }
         if (lane < size) {
             result[b0 + rank] = p.y;
-            if (WIDE) keys_out[b0 + rank] = p.x;
         }
         return;
     }
-    // bins: one to two per element, at most 2^q_max (q_max <= r: a bin never splits a key value)
-    uint32_t q = 32u - static_cast<uint32_t>(__builtin_clz(size - 1u));
+    uint32_t q = 32u - static_cast<uint32_t>(__builtin_clz(size - 1u));        // one to two bins per element
+    q = q < 6u ? 6u : q;
     q = q < q_min ? q_min : q;
     q = q > q_max ? q_max : q;
-    q = q > static_cast<uint32_t>(QMAX) ? static_cast<uint32_t>(QMAX) : q;
     const uint32_t nbw = (1u << q) / 2u;          // words of bins in use
     const uint32_t sub = r - q;                     // key bits below the bin
     const uint32_t submask = (1u << sub) - 1u;
@@ -310,7 +340,7 @@ __global__ __launch_bounds__(GSX2_NT) void k2_local(const uint2* __restrict__ pa
     return;
 #endif
     __syncthreads();
-    uint32_t comp[IPT], ba[IPT], fullkey[WIDE ? IPT : 1];
+    uint32_t comp[IPT], ba[IPT];
 #pragma unroll
     for (int i = 0; i < IPT; ++i) {
         if (static_cast<uint32_t>(i) < ni) {
@@ -318,7 +348,6 @@ __global__ __launch_bounds__(GSX2_NT) void k2_local(const uint2* __restrict__ pa
             const uint32_t low = pin[i].x & rmask;
             const uint32_t bin = low >> sub;
             comp[i] = ((low & submask) << idx_bits) | pin[i].y;
-            if (WIDE) fullkey[i] = pin[i].x;
             ba[i] = bin;
             if (e < size) {
                 const uint32_t sh = (bin & 1u) * 16u;
@@ -418,7 +447,6 @@ __global__ __launch_bounds__(GSX2_NT) void k2_local(const uint2* __restrict__ pa
             const uint32_t e = i * GSX2_NT + tid;
             if (e < size) {
                 if (ba[i] >> 31) s_comp[ba[i] & 0x7FFFFFFFu] = comp[i];
-                if (WIDE) keys_out[b0 + (ba[i] & 0x7FFFFFFFu)] = fullkey[i];
             }
         }
     }
@@ -430,9 +458,8 @@ __global__ __launch_bounds__(GSX2_NT) void k2_local(const uint2* __restrict__ pa
 // One workgroup per listed bucket: stable LSD radix, 8 bits a pass, over the 64-bit composite (key bits below the top
 // digit << idx_bits | index), ping-pong between the pair array and a scratch copy of it; the last pass writes the
 // permutation.  Tiles of 512 x 4 pairs, ranked by wave ballots like gsx_radix.hpp.
-template <bool WIDE>
-__global__ __launch_bounds__(GSX2_NT) void k2_big(uint2* pairs, uint2* scratch, const uint32_t* __restrict__ base, uint32_t r, uint32_t idx_bits,
-                                                  uint32_t* result, uint32_t* keys_out, const uint32_t* __restrict__ big_list,
+__global__ __launch_bounds__(GSX2_NT) void k2_big(uint2* pairs, uint2* scratch, const uint32_t* __restrict__ base, Gsx2Map mp, uint32_t idx_bits,
+                                                  uint32_t* result, const uint32_t* __restrict__ big_list,
                                                   const Gsx2Stats* __restrict__ stats) {
     constexpr int NW = GSX2_NT / 64, IT = 4;
     __shared__ uint32_t s_hist[256];
@@ -441,11 +468,12 @@ __global__ __launch_bounds__(GSX2_NT) void k2_big(uint2* pairs, uint2* scratch, 
     __shared__ uint32_t s_tmp[NW];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t n_big = stats->big_count < GSX2_BIG_LIST ? stats->big_count : GSX2_BIG_LIST;
-    const uint32_t rmask = r >= 32 ? 0xFFFFFFFFu : ((1u << r) - 1u);
-    const uint32_t total_bits = r + idx_bits;
-    const uint32_t n_pass = (total_bits + 7u) / 8u > 0u ? (total_bits + 7u) / 8u : 1u;
     for (uint32_t item = blockIdx.x; item < n_big; item += gridDim.x) {
         const uint32_t d = big_list[item];
+        const uint32_t r = gsx2_bucket_bits(d, mp);
+        const uint32_t rmask = (1u << r) - 1u;
+        const uint32_t total_bits = r + idx_bits;
+        const uint32_t n_pass = (total_bits + 7u) / 8u > 0u ? (total_bits + 7u) / 8u : 1u;
         const uint32_t b0 = base[d], size = base[d + 1] - b0;
         uint2* src = pairs + b0;
         uint2* dst = scratch + b0;
@@ -503,7 +531,6 @@ __global__ __launch_bounds__(GSX2_NT) void k2_big(uint2* pairs, uint2* scratch, 
                         const uint32_t o = s_w[wave][dg[i]] + rk[i];
                         if (last) {
                             result[b0 + o] = p[i].y;
-                            if (WIDE) keys_out[b0 + o] = p[i].x;
                         } else {
                             dst[o] = p[i];
                         }
@@ -520,11 +547,10 @@ __global__ __launch_bounds__(GSX2_NT) void k2_big(uint2* pairs, uint2* scratch, 
 // ---- host side ------------------------------------------------------------------------------------------------------
 struct Gsx2Plan {
     bool ok = false;
-    uint32_t r = 0, q = 0, q_min = 0, nd = 0, idx_bits = 0, low_mask = 0, ncols = 0;
+    Gsx2Map map = {0, 0, 0};
+    uint32_t nd = 0, idx_bits = 0, ncols = 0;
 };
 
-// low_span: largest value of the key bits this sort orders (key_span, or 2^27 - 1 under a gated top digit);
-// m_cap: host bound of the selection size; n_ids: ids are < n_ids.
 // Columns for up to m_cap keys: at least GSX2_MIN_COLS, a multiple of 64, none longer than GSX2_COLMAX keys; 0 = too many keys.
 static inline uint32_t gsx2_cols_for(uint64_t m_cap) {
     uint32_t ncols = GSX2_MIN_COLS;
@@ -532,12 +558,15 @@ static inline uint32_t gsx2_cols_for(uint64_t m_cap) {
     return ((m_cap + ncols - 1) / ncols + 255) / 256 * 256 > GSX2_COLMAX ? 0u : ncols;
 }
 
-static inline Gsx2Plan gsx2_plan(uint32_t low_span, uint32_t m_cap, uint64_t n_ids, uint32_t t_force = 0, bool any_size = false) {
+// key_span: largest relative key of the frame (host bound); m_cap: host bound of the selection size; ids are < n_ids.
+static inline Gsx2Plan gsx2_plan(uint32_t key_span, uint32_t m_cap, uint64_t n_ids, uint32_t t_force = 0, bool any_size = false) {
     Gsx2Plan p;
+    if (key_span > 0x7FFFFFFFu) return p;
+    const uint32_t fine_span = key_span < (1u << 25) ? key_span : (1u << 25) - 1u;
     uint32_t bits = 0;
-    while (bits < 32 && (static_cast<uint64_t>(low_span) >> bits) != 0) ++bits;
+    while ((fine_span >> bits) != 0) ++bits;
     uint32_t t = 10;
-    while (t < GSX2_MAX_T && (1536ull << t) < m_cap) ++t;        // ~1.5 K keys per bucket if they were spread evenly
+    while (t < GSX2_MAX_T - 1 && (1536ull << t) < m_cap) ++t;    // ~1.5 K keys per bucket if they were spread evenly over the fine region
     if (t_force) t = t_force;
     if (bits < t + 5) return p;                                   // narrow key range: the LSD passes are as good
     if (m_cap < (1u << 17) && !any_size) return p;                // small sorts are launch-bound either way
@@ -545,19 +574,19 @@ static inline Gsx2Plan gsx2_plan(uint32_t low_span, uint32_t m_cap, uint64_t n_i
     const uint32_t ncols = gsx2_cols_for(m_cap);
     if (!ncols) return p;
     p.ncols = ncols;
-    p.r = bits - t;
-    p.q = p.r < GSX2_MAX_Q ? p.r : GSX2_MAX_Q;
-    p.nd = ((low_span >> p.r) + 1u + 127u) / 128u * 128u;
+    p.map.r0 = bits - t;
+    if (p.map.r0 > 22u) return p;
+    p.map.nf = 23u - p.map.r0;
+    p.map.base = (1u << 25) >> p.map.r0;
+    p.nd = (gsx2_bucket(key_span, p.map) + 1u + 127u) / 128u * 128u;
     if (p.nd > GSX2_MAX_D) return p;
     uint32_t ib = 1;
     while (ib < 32 && (n_ids - 1) >> ib) ++ib;
     p.idx_bits = ib;
-    // k2_local packs the key bits below its bin and the index into one word: at least q_min bits must go into the bin
-    p.q_min = p.r + ib > 32 ? p.r + ib - 32 : 0u;
-    if (p.q_min < 6) p.q_min = 6;
-    if (p.q_min > p.q) p.q_min = p.q;
-    if ((p.r - p.q_min) + ib > 32) return p;
-    p.low_mask = bits >= 32 ? 0xFFFFFFFFu : ((1u << bits) - 1u);
+    // k2_local packs the key bits below its bin and the index into one word: the fine buckets must allow that
+    // (coarser buckets that cannot are sorted by k2_big when they hold more than a wave's worth)
+    const uint32_t q_min = p.map.r0 + ib > 32 ? p.map.r0 + ib - 32 : 0u;
+    if (q_min > 12u || q_min > p.map.r0) return p;
     p.ok = true;
     return p;
 }

@@ -95,6 +95,9 @@ typedef struct gsx_timings {
     uint64_t raster_staged;  /* profiling level 1: (tile, splat) pairs the rasterizer staged before their tile was saturated (of tile_pairs binned) */
     uint32_t render_capped;  /* 1 if the last frame binned every tile only up to its predicted saturation depth (option "tile_caps") */
     uint32_t render_redos;   /* continuations that supplied pairs a cap had withheld from a tile that did not saturate (0 as a rule) */
+    uint32_t sort_form;      /* 1 = stable LSD radix passes (count, scan, scatter per digit); 2 = the two-pass form: keys + top-digit counts,
+                                column scan, partition, in-LDS bucket sort (sort_passes = 2, scatter_ms = partition + bucket sort) */
+    uint32_t reserved0;
 } gsx_timings;
 
 /* ---- lifecycle (replaces Renderer::init device bring-up, renderer.cpp:3-100) ---- */
@@ -109,6 +112,8 @@ int gsx_sync(gsx_ctx* ctx);
  * sort runs on the main stream instead of beside the previous frame (see gsx_sort), so the bracket times the kernel, not
  * its share of a GPU it splits with the rasterizer.  The samples go through a ring of event pairs, so frames can be queued
  * back to back without reading anything in between; gsx_get_scatter_samples returns what has accumulated. */
+/* With the two-pass form of the depth sort (gsx_timings.sort_form == 2) the "passes" a sample brackets are 0 = the partition
+ * kernel and 1 = the bucket-sort kernels. */
 int gsx_set_profiling(gsx_ctx* ctx, int enabled);
 int gsx_get_timings(gsx_ctx* ctx, gsx_timings* out);
 /* Profiling level 2 (no counterpart in the reference): per radix pass p < 4 of the depth sort, the summed
@@ -127,6 +132,11 @@ int gsx_get_sort_samples(gsx_ctx* ctx, double* sum_ms, uint32_t* sorts, int rese
  *                   last frame, the default takes everything behind that window in one iteration)
  *   "no_history"    1 = always pre-queue iterations for the whole selection (default: only as many ranks as
  *                   the last 8 frames needed before every tile was saturated, +25 %; the rest runs on demand)
+ *   "sort_algo"     form of the depth sort: 0 = automatic (default: two passes over HBM -- a partition on the top <= 13 key bits, then
+ *                   every bucket finished inside LDS -- for selections of 2^17 .. ~2.4e7 splats whose key range is wide enough;
+ *                   the three 9-bit LSD radix passes otherwise, and for some frames after a sort that found most keys in
+ *                   buckets too dense for LDS), 1 = LSD passes only, 2 = two-pass whenever its plan allows, at any size.
+ *                   Same permutation either way (distance descending, index ascending).
  *   "async_sort"    0 = queue LOD cuts and depth sorts on the main stream, behind the frame in flight (default 1: on a
  *                   stream of their own, beside it; same results)
  *   "frames_in_flight"  1 = wait for frame k before queuing frame k + 1 (default 2: frame k + 1 is binned and rasterized on a

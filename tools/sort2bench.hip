@@ -39,7 +39,8 @@ int main(int argc, char** argv) {
         pos[i] = make_float4(x, y, z, 1.f);
     }
     if (scene == "equal") { pos[0] = make_float4(3, 3, -3, 1); pos[1] = make_float4(0, 0, 3, 1); }   // (a key range wide enough for the plan)
-    const float cx = 0.f, cy = 0.f, cz = 5.f;
+    const bool inside = argc > 5 && atoi(argv[5]);
+    const float cx = inside ? 0.4f : 0.f, cy = inside ? -0.3f : 0.f, cz = inside ? 0.9f : 5.f;
     std::vector<uint32_t> hkey(n);
     float dmin = 1e30f, dmax = 0.f;
     for (uint32_t i = 0; i < n; ++i) {
@@ -48,10 +49,10 @@ int main(int argc, char** argv) {
         hkey[i] = host_key(d);
         dmin = std::min(dmin, d); dmax = std::max(dmax, d);
     }
-    const uint32_t key_lo = host_key(dmax * 1.00001f), key_span = host_key(dmin * 0.99999f) - key_lo;
+    const uint32_t key_lo = host_key(dmax * 1.00001f), key_span = host_key(inside ? 0.f : dmin * 0.99999f) - key_lo;   // (inside the box the host can only promise distance 0)
     const Gsx2Plan plan = gsx2_plan(key_span, n, n, argc > 4 ? (uint32_t)atoi(argv[4]) : 0u);
-    printf("n=%u scene=%s d in [%.3f, %.3f] key_span=0x%x plan ok=%d r=%u q=%u..%u nd=%u idx_bits=%u ncols=%u\n", n, scene.c_str(), dmin, dmax, key_span, plan.ok, plan.r,
-           plan.q_min, plan.q, plan.nd, plan.idx_bits, plan.ncols);
+    printf("n=%u scene=%s d in [%.3f, %.3f] key_span=0x%x plan ok=%d r0=%u nd=%u idx_bits=%u ncols=%u\n", n, scene.c_str(), dmin, dmax, key_span, plan.ok, plan.map.r0,
+           plan.nd, plan.idx_bits, plan.ncols);
     if (!plan.ok) return 2;
     hipStream_t st; CK(hipStreamCreate(&st));
     float4* d_pos; uint32_t *d_keys, *d_m, *d_pre, *d_tot, *d_base, *d_res, *d_big, *d_keys_out; uint16_t* d_cnt; uint2 *d_pairs, *d_scratch;
@@ -67,18 +68,18 @@ int main(int argc, char** argv) {
     std::vector<float> t[7];
     for (int rep = 0; rep < reps + 3; ++rep) {
         CK(hipEventRecord(ev[0], st));
-        hipLaunchKernelGGL(k2_keygen_hist<true>, dim3(plan.ncols), dim3(GSX2_NT), 0, st, d_pos, nullptr, d_m, cx, cy, cz, key_lo, key_span, plan.low_mask, plan.r, plan.nd, 0u,
+        hipLaunchKernelGGL(k2_keygen_hist<true>, dim3(plan.ncols), dim3(GSX2_NT), 0, st, d_pos, nullptr, d_m, cx, cy, cz, key_lo, key_span, plan.map, plan.nd,
                            d_keys, d_cnt, d_flags, nullptr, d_stats);
         CK(hipEventRecord(ev[1], st));
         hipLaunchKernelGGL(k2_scan, dim3(plan.nd / 16), dim3(512), 0, st, d_cnt, d_pre, d_tot, plan.nd, plan.ncols);
         CK(hipEventRecord(ev[2], st));
-        hipLaunchKernelGGL(k2_partition<true>, dim3(plan.ncols), dim3(GSX2_PNT), 0, st, d_keys, nullptr, d_m, plan.low_mask, plan.r, plan.nd, d_cnt, d_pre, d_tot, d_base, d_pairs, d_stats, d_flags);
+        hipLaunchKernelGGL(k2_partition<true>, dim3(plan.ncols), dim3(GSX2_PNT), 0, st, d_keys, nullptr, d_m, plan.map, plan.nd, d_cnt, d_pre, d_tot, d_base, d_pairs, d_stats, d_flags);
         CK(hipEventRecord(ev[3], st));
-        hipLaunchKernelGGL((k2_local<GSX2_IPT, false>), dim3(plan.nd), dim3(GSX2_NT), 0, st, d_pairs, d_base, plan.nd, plan.r, plan.q_min, plan.q, plan.idx_bits, d_res, d_keys_out, d_big, d_stats, d_flags);
+        hipLaunchKernelGGL((k2_local<GSX2_IPT>), dim3(plan.nd), dim3(GSX2_NT), 0, st, d_pairs, d_base, plan.nd, plan.map, plan.idx_bits, d_res, d_big, d_stats, d_flags);
         CK(hipEventRecord(ev[6], st));
-        hipLaunchKernelGGL((k2_local<8, false>), dim3(plan.nd), dim3(GSX2_NT), 0, st, d_pairs, d_base, plan.nd, plan.r, plan.q_min, plan.q, plan.idx_bits, d_res, d_keys_out, d_big, d_stats, d_flags);
+        hipLaunchKernelGGL((k2_local<8>), dim3(plan.nd), dim3(GSX2_NT), 0, st, d_pairs, d_base, plan.nd, plan.map, plan.idx_bits, d_res, d_big, d_stats, d_flags);
         CK(hipEventRecord(ev[4], st));
-        hipLaunchKernelGGL(k2_big<false>, dim3(256), dim3(GSX2_NT), 0, st, d_pairs, d_scratch, d_base, plan.r, plan.idx_bits, d_res, d_keys_out, d_big, d_stats);
+        hipLaunchKernelGGL(k2_big, dim3(256), dim3(GSX2_NT), 0, st, d_pairs, d_scratch, d_base, plan.map, plan.idx_bits, d_res, d_big, d_stats);
         CK(hipEventRecord(ev[5], st));
         CK(hipStreamSynchronize(st));
         CK(hipGetLastError());
