@@ -323,11 +323,10 @@ static int launch_sort_in(gsx_ctx* c, const GsxSortBuffers& sb, hipStream_t st) 
         e0 = profiling ? c->ev[EV_X0 + 2] : samp_a[1];
         e1 = profiling ? c->ev[EV_X0 + 3] : samp_b[1];
         if (e0) GSX_HIP(c, hipEventRecord(e0, st));
-        hipLaunchKernelGGL((k2_local<GSX2_IPT>), dim3(p2.nd), dim3(GSX2_NT), 0, st, c->s2_pairs, w.base, p2.nd, p2.map, p2.idx_bits, result, w.big_list,
-                           w.stats, c->flags);
-        hipLaunchKernelGGL((k2_local<8>), dim3(p2.nd), dim3(GSX2_NT), 0, st, c->s2_pairs, w.base, p2.nd, p2.map, p2.idx_bits, result, w.big_list, w.stats,
-                           c->flags);
-        hipLaunchKernelGGL(k2_big, dim3(256), dim3(GSX2_NT), 0, st, c->s2_pairs, c->s2_scratch, w.base, p2.map, p2.idx_bits, result, w.big_list, w.stats);
+        // three instances by bucket size; the last one also sorts what does not fit LDS (through the scratch twin of the pairs)
+        hipLaunchKernelGGL((k2_local<GSX2_IPT>), dim3(p2.nd), dim3(GSX2_NT), 0, st, c->s2_pairs, c->s2_scratch, w.base, p2.nd, p2.map, p2.idx_bits, result);
+        hipLaunchKernelGGL((k2_local<16>), dim3(p2.nd), dim3(GSX2_NT), 0, st, c->s2_pairs, c->s2_scratch, w.base, p2.nd, p2.map, p2.idx_bits, result);
+        hipLaunchKernelGGL((k2_local<8>), dim3(p2.nd), dim3(GSX2_NT), 0, st, c->s2_pairs, c->s2_scratch, w.base, p2.nd, p2.map, p2.idx_bits, result);
         if (e1) GSX_HIP(c, hipEventRecord(e1, st));
         // bucket statistics for the next sorts' choice of form (read when the copy has landed, never waited for)
         if (!c->s2_stats_rec) {

@@ -36,13 +36,12 @@
 #define GSX2_CAP 12288                   // pairs of the largest bucket k2_local sorts in LDS
 #define GSX2_IPT (GSX2_CAP / GSX2_NT)
 #define GSX2_MAX_Q 13                    // bits of k2_local's bins at most (2^13 packed 16-bit bins = 16 KB)
-#define GSX2_BIG_LIST 4096               // oversized buckets remembered per sort (more: flag)
 
 struct Gsx2Stats {
     uint32_t big_buckets;    // buckets larger than GSX2_CAP in the latest sort (k2_partition, block 0)
     uint32_t big_keys;       // keys in them
     uint32_t max_bucket;
-    uint32_t big_count;      // list length (k2_local appends, k2_big consumes; zeroed by k2_keygen_hist)
+    uint32_t reserved;
 };
 
 // Bucket of a (relative) key.  Keys are inverted float bit patterns, so 2^23 consecutive key values span a factor of two in
@@ -87,7 +86,6 @@ __global__ __launch_bounds__(GSX2_NT) void k2_keygen_hist(const float4* __restri
     const uint32_t m = *m_ptr;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         if (m_copy) *m_copy = m;
-        stats->big_count = 0;
     }
     for (uint32_t t = threadIdx.x; t < nd; t += GSX2_NT) s_hist[t] = 0;
     __syncthreads();
@@ -136,13 +134,13 @@ __global__ __launch_bounds__(512) void k2_scan(const uint16_t* __restrict__ cnt,
     const uint32_t* cnt32 = reinterpret_cast<const uint32_t*>(cnt);
     const uint64_t row = nd >> 1;                                    // words per column
     const uint64_t at0 = static_cast<uint64_t>(c0) * row + (d0 >> 1);
-    uint32_t s0 = 0, s1 = 0;
+    uint32_t s0 = 0, s1 = 0, keep[8];
     for (uint32_t j0 = 0; j0 < cl; j0 += 8) {
         uint32_t w[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) w[j] = (j0 + j < cl) ? cnt32[at0 + (j0 + j) * row] : 0u;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { s0 += w[j] & 0xFFFFu; s1 += w[j] >> 16; }
+        for (int j = 0; j < 8; ++j) { s0 += w[j] & 0xFFFFu; s1 += w[j] >> 16; keep[j] = w[j]; }
     }
     s_part[ch][pr] = make_uint2(s0, s1);
     __syncthreads();
@@ -156,7 +154,7 @@ __global__ __launch_bounds__(512) void k2_scan(const uint16_t* __restrict__ cnt,
     for (uint32_t j0 = 0; j0 < cl; j0 += 8) {
         uint32_t w[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) w[j] = (j0 + j < cl) ? cnt32[at0 + (j0 + j) * row] : 0u;
+        for (int j = 0; j < 8; ++j) w[j] = (cl <= 8u) ? keep[j] : ((j0 + j < cl) ? cnt32[at0 + (j0 + j) * row] : 0u);   // (second sweep: L2)
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             if (j0 + j < cl) pre2[at0 + (j0 + j) * row] = make_uint2(r0, r1);
@@ -269,16 +267,21 @@ __global__ __launch_bounds__(GSX2_PNT) void k2_partition(const uint32_t* __restr
 }
 
 // ---- D: one bucket per workgroup, finished in LDS -----------------------------------------------------------------
-// Element word in LDS: (key bits below the bin << idx_bits) | index  (the host checks that this fits 32 bits).
-// Two instances share the buckets by size: IPT = 8 (up to 4096 pairs, 24 KB of LDS: four workgroups per CU) takes the
-// many ordinary buckets, IPT = GSX2_IPT (up to GSX2_CAP) the few large ones and lists what exceeds even that for k2_big.
+// Element word in LDS: (key bits below the bin << idx_bits) | index.  Three instances share the buckets by size, so that
+// the many ordinary buckets do not pay for the LDS of the largest: IPT = 8 (up to 4096 pairs, 32 KB: four workgroups per
+// CU), IPT = 16 (up to 8192, 48 KB: three per CU), and IPT = GSX2_IPT (up to GSX2_CAP; 64 KB), whose workgroups also take
+// what nothing sorts in LDS -- a larger bucket, or a coarse bucket near the camera whose key bits do not fit the word --
+// through gsx2_big_bucket (defined below).
+__device__ __forceinline__ void gsx2_big_bucket(uint2* pairs, uint2* scratch, uint32_t b0, uint32_t size, uint32_t r, uint32_t idx_bits,
+                                                uint32_t* result, uint32_t* lds);
+
 template <int IPT>
-__global__ __launch_bounds__(GSX2_NT) void k2_local(const uint2* __restrict__ pairs, const uint32_t* __restrict__ base, uint32_t nd,
-                                                    Gsx2Map mp, uint32_t idx_bits, uint32_t* __restrict__ result,
-                                                    uint32_t* __restrict__ big_list,
-                                                    Gsx2Stats* __restrict__ stats, GsxDevFlags* __restrict__ flags) {
-    constexpr bool LARGE = IPT > 8;
-    constexpr int QMAX = LARGE ? GSX2_MAX_Q : 12;
+__global__ __launch_bounds__(GSX2_NT) __attribute__((amdgpu_waves_per_eu(IPT == 8 ? 8 : (IPT == 16 ? 6 : 4), IPT == 8 ? 8 : (IPT == 16 ? 6 : 4))))
+void k2_local(uint2* pairs, uint2* scratch, const uint32_t* __restrict__ base, uint32_t nd, Gsx2Map mp, uint32_t idx_bits,
+              uint32_t* __restrict__ result) {
+    constexpr bool REST = IPT > 16;                  // the instance that also takes what does not fit LDS
+    constexpr int QMAX = GSX2_MAX_Q;
+    constexpr uint32_t LO = IPT == 8 ? 0u : (IPT == 16 ? 8u * GSX2_NT : 16u * GSX2_NT), HI = IPT * GSX2_NT;
     __shared__ uint32_t s_bins[(1 << QMAX) / 2];    // packed 16-bit: counts, then exclusive starts
     __shared__ uint32_t s_comp[IPT * GSX2_NT];
     __shared__ uint32_t s_tmp[GSX2_NT / 64];
@@ -286,21 +289,18 @@ __global__ __launch_bounds__(GSX2_NT) void k2_local(const uint2* __restrict__ pa
     const uint32_t d = blockIdx.x;
     const uint32_t b0 = base[d], size = base[d + 1] - b0;
     if (size == 0) return;
-    if (LARGE ? size <= 8u * GSX2_NT : size > 8u * GSX2_NT) return;      // the other instance's bucket
     const uint32_t r = gsx2_bucket_bits(d, mp);
     const uint32_t rmask = (1u << r) - 1u;
     const uint32_t idx_mask = idx_bits >= 32 ? 0xFFFFFFFFu : ((1u << idx_bits) - 1u);
     // bins: at most 2^QMAX and never finer than a key value; the key bits below the bin share a word with the index
     const uint32_t q_max = r < static_cast<uint32_t>(QMAX) ? r : static_cast<uint32_t>(QMAX);
     const uint32_t q_min = r + idx_bits > 32u ? r + idx_bits - 32u : 0u;
-    if (size > GSX2_CAP || (size > 64u && q_min > q_max)) {
-        if (tid == 0) {
-            const uint32_t slot = atomicAdd(&stats->big_count, 1u);
-            if (slot < GSX2_BIG_LIST) big_list[slot] = d;
-            else atomicOr(&flags->key_bound, 2u);      // (cannot happen below 2^25 keys)
-        }
+    const bool unpackable = size > 64u && q_min > (r < static_cast<uint32_t>(GSX2_MAX_Q) ? r : static_cast<uint32_t>(GSX2_MAX_Q));
+    if (size > GSX2_CAP || unpackable) {
+        if (REST) gsx2_big_bucket(pairs, scratch, b0, size, r, idx_bits, result, s_comp);
         return;
     }
+    if (size <= LO || size > HI) return;            // another instance's bucket
     if (size <= 64) {          // one wave, rank by counting over the whole bucket
         if (tid >= 64) return;
         uint2 p = make_uint2(0, 0);
@@ -455,92 +455,82 @@ __global__ __launch_bounds__(GSX2_NT) void k2_local(const uint2* __restrict__ pa
 }
 
 // ---- E: buckets beyond LDS ------------------------------------------------------------------------------------------
-// One workgroup per listed bucket: stable LSD radix, 8 bits a pass, over the 64-bit composite (key bits below the top
+// One workgroup sorts one such bucket: stable LSD radix, 8 bits a pass, over the 64-bit composite (key bits below the top
 // digit << idx_bits | index), ping-pong between the pair array and a scratch copy of it; the last pass writes the
-// permutation.  Tiles of 512 x 4 pairs, ranked by wave ballots like gsx_radix.hpp.
-__global__ __launch_bounds__(GSX2_NT) void k2_big(uint2* pairs, uint2* scratch, const uint32_t* __restrict__ base, Gsx2Map mp, uint32_t idx_bits,
-                                                  uint32_t* result, const uint32_t* __restrict__ big_list,
-                                                  const Gsx2Stats* __restrict__ stats) {
+// permutation.  Tiles of 512 x 4 pairs, ranked by wave ballots like gsx_radix.hpp.  `lds`: 10 KB + 16 words.
+__device__ __forceinline__ void gsx2_big_bucket(uint2* pairs, uint2* scratch, uint32_t b0, uint32_t size, uint32_t r, uint32_t idx_bits,
+                                                uint32_t* result, uint32_t* lds) {
     constexpr int NW = GSX2_NT / 64, IT = 4;
-    __shared__ uint32_t s_hist[256];
-    __shared__ uint32_t s_run[256];
-    __shared__ uint32_t s_w[NW][256];
-    __shared__ uint32_t s_tmp[NW];
+    uint32_t* s_hist = lds;
+    uint32_t* s_run = lds + 256;
+    uint32_t (*s_w)[256] = reinterpret_cast<uint32_t (*)[256]>(lds + 512);
+    uint32_t* s_tmp = lds + 512 + NW * 256;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const uint32_t n_big = stats->big_count < GSX2_BIG_LIST ? stats->big_count : GSX2_BIG_LIST;
-    for (uint32_t item = blockIdx.x; item < n_big; item += gridDim.x) {
-        const uint32_t d = big_list[item];
-        const uint32_t r = gsx2_bucket_bits(d, mp);
-        const uint32_t rmask = (1u << r) - 1u;
-        const uint32_t total_bits = r + idx_bits;
-        const uint32_t n_pass = (total_bits + 7u) / 8u > 0u ? (total_bits + 7u) / 8u : 1u;
-        const uint32_t b0 = base[d], size = base[d + 1] - b0;
-        uint2* src = pairs + b0;
-        uint2* dst = scratch + b0;
-        for (uint32_t pass = 0; pass < n_pass; ++pass) {
-            const uint32_t shift = pass * 8u;
-            const bool last = pass + 1 == n_pass;
-            auto digit_of = [&](uint2 p) -> uint32_t {
-                const unsigned long long comp = (static_cast<unsigned long long>(p.x & rmask) << idx_bits) | p.y;
-                return static_cast<uint32_t>(comp >> shift) & 255u;
-            };
-            if (tid < 256) s_hist[tid] = 0;
+    const uint32_t rmask = (1u << r) - 1u;
+    const uint32_t total_bits = r + idx_bits;
+    const uint32_t n_pass = (total_bits + 7u) / 8u > 0u ? (total_bits + 7u) / 8u : 1u;
+    uint2* src = pairs + b0;
+    uint2* dst = scratch + b0;
+    for (uint32_t pass = 0; pass < n_pass; ++pass) {
+        const uint32_t shift = pass * 8u;
+        const bool last = pass + 1 == n_pass;
+        auto digit_of = [&](uint2 p) -> uint32_t {
+            const unsigned long long comp = (static_cast<unsigned long long>(p.x & rmask) << idx_bits) | p.y;
+            return static_cast<uint32_t>(comp >> shift) & 255u;
+        };
+        __syncthreads();
+        if (tid < 256) s_hist[tid] = 0;
+        __syncthreads();
+        for (uint32_t e = tid; e < size; e += GSX2_NT) atomicAdd(&s_hist[digit_of(src[e])], 1u);
+        __syncthreads();
+        {
+            const uint32_t v = tid < 256 ? s_hist[tid] : 0u;
+            const uint32_t ex = gsx_block_excl_scan<GSX2_NT>(v, s_tmp, nullptr);
+            if (tid < 256) s_run[tid] = ex;
+        }
+        __syncthreads();
+        for (uint32_t tb = 0; tb < size; tb += GSX2_NT * IT) {
+            for (uint32_t t = tid; t < NW * 256; t += GSX2_NT) (&s_w[0][0])[t] = 0;
             __syncthreads();
-            for (uint32_t e = tid; e < size; e += GSX2_NT) atomicAdd(&s_hist[digit_of(src[e])], 1u);
-            __syncthreads();
-            {
-                const uint32_t v = tid < 256 ? s_hist[tid] : 0u;
-                const uint32_t ex = gsx_block_excl_scan<GSX2_NT>(v, s_tmp, nullptr);
-                if (tid < 256) s_run[tid] = ex;
+            uint2 p[IT];
+            uint32_t dg[IT], rk[IT];
+            bool ok[IT];
+#pragma unroll
+            for (int i = 0; i < IT; ++i) {      // wave-striped so that (wave, item, lane) order is element order
+                const uint32_t e = tb + wave * (64 * IT) + i * 64 + lane;
+                ok[i] = e < size;
+                p[i] = ok[i] ? src[e] : make_uint2(0, 0);
+                dg[i] = ok[i] ? digit_of(p[i]) : 256u;      // 256: matches no real digit
+                const uint64_t act = __builtin_amdgcn_ballot_w64(ok[i]);
+                uint64_t peers = gsx_match_digit(dg[i] & 255u, 8) & (ok[i] ? act : ~act);
+                const uint32_t lower = gsx_mbcnt(peers);
+                uint32_t prev = 0;
+                if (ok[i] && lower == 0) prev = atomicAdd(&s_w[wave][dg[i]], static_cast<uint32_t>(__popcll(peers)));
+                rk[i] = static_cast<uint32_t>(__shfl(prev, static_cast<int>(__builtin_ctzll(peers)))) + lower;
             }
             __syncthreads();
-            for (uint32_t tb = 0; tb < size; tb += GSX2_NT * IT) {
-                for (uint32_t t = tid; t < NW * 256; t += GSX2_NT) (&s_w[0][0])[t] = 0;
-                __syncthreads();
-                uint2 p[IT];
-                uint32_t dg[IT], rk[IT];
-                bool ok[IT];
+            if (tid < 256) {
+                uint32_t acc = s_run[tid];
 #pragma unroll
-                for (int i = 0; i < IT; ++i) {      // wave-striped so that (wave, item, lane) order is element order
-                    const uint32_t e = tb + wave * (64 * IT) + i * 64 + lane;
-                    ok[i] = e < size;
-                    p[i] = ok[i] ? src[e] : make_uint2(0, 0);
-                    dg[i] = ok[i] ? digit_of(p[i]) : 256u;      // 256: matches no real digit
-                    const uint64_t act = __builtin_amdgcn_ballot_w64(ok[i]);
-                    uint64_t peers = gsx_match_digit(dg[i] & 255u, 8) & (ok[i] ? act : ~act);
-                    const uint32_t lower = gsx_mbcnt(peers);
-                    uint32_t prev = 0;
-                    if (ok[i] && lower == 0) prev = atomicAdd(&s_w[wave][dg[i]], static_cast<uint32_t>(__popcll(peers)));
-                    rk[i] = static_cast<uint32_t>(__shfl(prev, static_cast<int>(__builtin_ctzll(peers)))) + lower;
+                for (int w = 0; w < NW; ++w) {
+                    const uint32_t c = s_w[w][tid];
+                    s_w[w][tid] = acc;
+                    acc += c;
                 }
-                __syncthreads();
-                if (tid < 256) {
-                    uint32_t acc = s_run[tid];
-#pragma unroll
-                    for (int w = 0; w < NW; ++w) {
-                        const uint32_t c = s_w[w][tid];
-                        s_w[w][tid] = acc;
-                        acc += c;
-                    }
-                    s_run[tid] = acc;
-                }
-                __syncthreads();
-#pragma unroll
-                for (int i = 0; i < IT; ++i) {
-                    if (ok[i]) {
-                        const uint32_t o = s_w[wave][dg[i]] + rk[i];
-                        if (last) {
-                            result[b0 + o] = p[i].y;
-                        } else {
-                            dst[o] = p[i];
-                        }
-                    }
-                }
-                __syncthreads();
+                s_run[tid] = acc;
             }
-            uint2* t = src; src = dst; dst = t;
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < IT; ++i) {
+                if (ok[i]) {
+                    const uint32_t o = s_w[wave][dg[i]] + rk[i];
+                    if (last) result[b0 + o] = p[i].y;
+                    else dst[o] = p[i];
+                }
+            }
             __syncthreads();
         }
+        uint2* t = src; src = dst; dst = t;
     }
 }
 
@@ -594,13 +584,13 @@ static inline Gsx2Plan gsx2_plan(uint32_t key_span, uint32_t m_cap, uint64_t n_i
 // Workspace beside the pair arrays: count matrix (2 B per column x bucket), prefix matrix (4 B), totals, bases, list, stats.
 struct Gsx2Workspace {
     uint16_t* cnt;
-    uint32_t *pre, *totals, *base, *big_list;
+    uint32_t *pre, *totals, *base;
     Gsx2Stats* stats;
 };
 static inline uint64_t gsx2_ws_bytes(uint64_t cap) {
     uint32_t ncols = gsx2_cols_for(cap);
     if (!ncols) ncols = GSX2_MIN_COLS;      // (such a scene never takes this path; keep the layout valid)
-    return static_cast<uint64_t>(ncols) * GSX2_MAX_D * (2 + 4) + (GSX2_MAX_D * 2 + 64 + GSX2_BIG_LIST) * 4ull + 256;
+    return static_cast<uint64_t>(ncols) * GSX2_MAX_D * (2 + 4) + (GSX2_MAX_D * 2 + 64) * 4ull + 256;
 }
 static inline Gsx2Workspace gsx2_ws_carve(unsigned char* ws, uint64_t cap) {
     uint32_t ncols = gsx2_cols_for(cap);
@@ -610,7 +600,6 @@ static inline Gsx2Workspace gsx2_ws_carve(unsigned char* ws, uint64_t cap) {
     w.cnt = reinterpret_cast<uint16_t*>(ws + static_cast<uint64_t>(ncols) * GSX2_MAX_D * 4);
     w.totals = reinterpret_cast<uint32_t*>(ws + static_cast<uint64_t>(ncols) * GSX2_MAX_D * 6);
     w.base = w.totals + GSX2_MAX_D;
-    w.big_list = w.base + GSX2_MAX_D + 64;
-    w.stats = reinterpret_cast<Gsx2Stats*>(w.big_list + GSX2_BIG_LIST);
+    w.stats = reinterpret_cast<Gsx2Stats*>(w.base + GSX2_MAX_D + 64);
     return w;
 }

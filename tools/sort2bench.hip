@@ -55,12 +55,12 @@ int main(int argc, char** argv) {
            plan.nd, plan.idx_bits, plan.ncols);
     if (!plan.ok) return 2;
     hipStream_t st; CK(hipStreamCreate(&st));
-    float4* d_pos; uint32_t *d_keys, *d_m, *d_pre, *d_tot, *d_base, *d_res, *d_big, *d_keys_out; uint16_t* d_cnt; uint2 *d_pairs, *d_scratch;
+    float4* d_pos; uint32_t *d_keys, *d_m, *d_pre, *d_tot, *d_base, *d_res, *d_keys_out; uint16_t* d_cnt; uint2 *d_pairs, *d_scratch;
     GsxDevFlags* d_flags; Gsx2Stats* d_stats;
     CK(hipMalloc(&d_pos, (size_t)n * 16)); CK(hipMalloc(&d_keys, (size_t)n * 4)); CK(hipMalloc(&d_m, 4));
     CK(hipMalloc(&d_cnt, (size_t)GSX2_MAX_COLS * GSX2_MAX_D * 2)); CK(hipMalloc(&d_pre, (size_t)GSX2_MAX_COLS * GSX2_MAX_D * 4));
     CK(hipMalloc(&d_tot, GSX2_MAX_D * 4)); CK(hipMalloc(&d_base, (GSX2_MAX_D + 64) * 4)); CK(hipMalloc(&d_res, (size_t)n * 4)); CK(hipMalloc(&d_keys_out, (size_t)n * 4));
-    CK(hipMalloc(&d_big, GSX2_BIG_LIST * 4)); CK(hipMalloc(&d_pairs, (size_t)n * 8)); CK(hipMalloc(&d_scratch, (size_t)n * 8));
+    CK(hipMalloc(&d_pairs, (size_t)n * 8)); CK(hipMalloc(&d_scratch, (size_t)n * 8));
     CK(hipMalloc(&d_flags, sizeof(GsxDevFlags))); CK(hipMalloc(&d_stats, sizeof(Gsx2Stats)));
     CK(hipMemset(d_flags, 0, sizeof(GsxDevFlags))); CK(hipMemset(d_stats, 0, sizeof(Gsx2Stats)));
     CK(hipMemcpy(d_pos, pos.data(), (size_t)n * 16, hipMemcpyHostToDevice)); CK(hipMemcpy(d_m, &n, 4, hipMemcpyHostToDevice));
@@ -75,11 +75,11 @@ int main(int argc, char** argv) {
         CK(hipEventRecord(ev[2], st));
         hipLaunchKernelGGL(k2_partition<true>, dim3(plan.ncols), dim3(GSX2_PNT), 0, st, d_keys, nullptr, d_m, plan.map, plan.nd, d_cnt, d_pre, d_tot, d_base, d_pairs, d_stats, d_flags);
         CK(hipEventRecord(ev[3], st));
-        hipLaunchKernelGGL((k2_local<GSX2_IPT>), dim3(plan.nd), dim3(GSX2_NT), 0, st, d_pairs, d_base, plan.nd, plan.map, plan.idx_bits, d_res, d_big, d_stats, d_flags);
+        hipLaunchKernelGGL((k2_local<GSX2_IPT>), dim3(plan.nd), dim3(GSX2_NT), 0, st, d_pairs, d_scratch, d_base, plan.nd, plan.map, plan.idx_bits, d_res);
         CK(hipEventRecord(ev[6], st));
-        hipLaunchKernelGGL((k2_local<8>), dim3(plan.nd), dim3(GSX2_NT), 0, st, d_pairs, d_base, plan.nd, plan.map, plan.idx_bits, d_res, d_big, d_stats, d_flags);
+        hipLaunchKernelGGL((k2_local<16>), dim3(plan.nd), dim3(GSX2_NT), 0, st, d_pairs, d_scratch, d_base, plan.nd, plan.map, plan.idx_bits, d_res);
         CK(hipEventRecord(ev[4], st));
-        hipLaunchKernelGGL(k2_big, dim3(256), dim3(GSX2_NT), 0, st, d_pairs, d_scratch, d_base, plan.map, plan.idx_bits, d_res, d_big, d_stats);
+        hipLaunchKernelGGL((k2_local<8>), dim3(plan.nd), dim3(GSX2_NT), 0, st, d_pairs, d_scratch, d_base, plan.nd, plan.map, plan.idx_bits, d_res);
         CK(hipEventRecord(ev[5], st));
         CK(hipStreamSynchronize(st));
         CK(hipGetLastError());
@@ -91,9 +91,9 @@ int main(int argc, char** argv) {
     auto med = [](std::vector<float> v) { std::sort(v.begin(), v.end()); return v[v.size() / 2] * 1e3f; };
     Gsx2Stats hs; CK(hipMemcpy(&hs, d_stats, sizeof hs, hipMemcpyDeviceToHost));
     GsxDevFlags hf; CK(hipMemcpy(&hf, d_flags, sizeof hf, hipMemcpyDeviceToHost));
-    printf("keygen+hist %.1f us  scan %.1f  partition %.1f  local %.1f (large-bucket instance %.1f)  big %.1f  | whole %.1f us = %.2f G splats/s (92 B/splat: %.2f of 8 TB/s)\n", med(t[0]), med(t[1]),
-           med(t[2]), med(t[3]), med(t[6]), med(t[4]), med(t[5]), n / med(t[5]) * 1e-3, 92.0 * n / (med(t[5]) * 1e-6) / 8e12);
-    printf("stats: big_buckets=%u big_keys=%u max_bucket=%u big_count=%u key_bound_flag=%u\n", hs.big_buckets, hs.big_keys, hs.max_bucket, hs.big_count, hf.key_bound);
+    printf("keygen+hist %.1f us  scan %.1f  partition %.1f  local: rest %.1f + mid %.1f + small %.1f  | whole %.1f us = %.2f G splats/s (92 B/splat: %.2f of 8 TB/s)\n", med(t[0]), med(t[1]),
+           med(t[2]), med(t[6]), med(t[3]) - med(t[6]), med(t[4]), med(t[5]), n / med(t[5]) * 1e-3, 92.0 * n / (med(t[5]) * 1e-6) / 8e12);
+    printf("stats: big_buckets=%u big_keys=%u max_bucket=%u key_bound_flag=%u\n", hs.big_buckets, hs.big_keys, hs.max_bucket, hf.key_bound);
     std::vector<uint32_t> res(n);
     CK(hipMemcpy(res.data(), d_res, (size_t)n * 4, hipMemcpyDeviceToHost));
     std::vector<uint32_t> ref(n);
