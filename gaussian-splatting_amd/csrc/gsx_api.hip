@@ -157,6 +157,7 @@ int gsx_destroy(gsx_ctx* c) {
     c->frame_pending = false;
     c->parked.frame_pending = false;
     if (c->comm_stream) (void)hipStreamSynchronize(c->comm_stream);
+    gsx_comm_detach_all(c);
     if (c->sort_stream) (void)hipStreamSynchronize(c->sort_stream);
     if (c->parked.fstream) (void)hipStreamSynchronize(c->parked.fstream);
     if (c->fstream) (void)hipStreamSynchronize(c->fstream);
@@ -631,8 +632,10 @@ int gsx_sort(gsx_ctx* c, const float cam_pos[3], uint32_t* idx_out_host) {
     if ((rc = gsx_launch_sort(c))) return rc;
     c->ev_recorded[EV_SORT1] = c->profiling;
     if (idx_out_host) {
-        GSX_HIP(c, hipMemcpyAsync(c->host_word, c->m_dev, 4, hipMemcpyDeviceToHost, c->stream));
+        // the size of THIS permutation: the word the key kernel wrote beside it, read once everything queued has been joined
+        // (the selection's own size word may still be written by a cut queued on the sort stream)
         if ((rc = check_flags(c))) return rc;
+        GSX_HIP(c, hipMemcpy(c->host_word, c->m_perm + c->perm_cur, 4, hipMemcpyDeviceToHost));
         const uint32_t m = *c->host_word;
         if (m) GSX_HIP(c, hipMemcpy(idx_out_host, c->perm[c->perm_cur], static_cast<uint64_t>(m) * 4, hipMemcpyDeviceToHost));
     }
@@ -659,8 +662,8 @@ int gsx_get_sorted_dev(gsx_ctx* c, const uint32_t** idx_dev, uint32_t* m) {
     if (!c->sorted_valid) { c->err = "no sorted permutation yet"; return GSX_E_STATE; }
     int rc = set_device(c);
     if (rc) return rc;
-    GSX_HIP(c, hipMemcpyAsync(c->host_word, c->m_dev, 4, hipMemcpyDeviceToHost, c->stream));
     if ((rc = check_flags(c))) return rc;
+    GSX_HIP(c, hipMemcpy(c->host_word, c->m_perm + c->perm_cur, 4, hipMemcpyDeviceToHost));
     *idx_dev = c->perm[c->perm_cur];
     *m = *c->host_word;
     return GSX_OK;

@@ -36,17 +36,22 @@ struct RcclApi {
     std::string error;
 };
 
+static void rccl_load(RcclApi& api);
+
+// Loaded once per process; a function-local static is initialised by exactly one thread (the others wait), so two host
+// threads creating communicators at the same time never see a half-filled table.
 RcclApi* rccl() {
-    static RcclApi api;
-    static bool tried = false;
-    if (tried) return &api;
-    tried = true;
+    static RcclApi api = [] { RcclApi a; rccl_load(a); return a; }();
+    return &api;
+}
+
+static void rccl_load(RcclApi& api) {
     const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     for (const char* n : names) {
         api.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
         if (api.handle) break;
     }
-    if (!api.handle) { api.error = std::string("cannot load librccl: ") + dlerror(); return &api; }
+    if (!api.handle) { api.error = std::string("cannot load librccl: ") + dlerror(); return; }
     bool ok = true;
     auto sym = [&](const char* name) { void* p = dlsym(api.handle, name); if (!p) { ok = false; api.error = std::string("librccl lacks ") + name; } return p; };
     api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(sym("ncclGetUniqueId"));
@@ -58,7 +63,6 @@ RcclApi* rccl() {
     api.Recv = reinterpret_cast<decltype(api.Recv)>(sym("ncclRecv"));
     api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(sym("ncclGetErrorString"));
     if (!ok) { dlclose(api.handle); api.handle = nullptr; }
-    return &api;
 }
 
 }  // namespace
@@ -133,20 +137,50 @@ int gsx_comm_init(gsx_ctx* c, const void* id128, int rank, int nranks, gsx_comm*
         const ncclResult_t r = api->CommInitRank(&m->comm, nranks, id, rank);   // collective: returns when every rank has joined
         if (r != ncclSuccess) { c->err = std::string("ncclCommInitRank: ") + api->GetErrorString(r); delete m; return GSX_E_HIP; }
     }
+    // the context keeps track of its communicators so that gsx_destroy can release one that is still alive
+    bool filed = false;
+    for (auto& slot : c->comms)
+        if (!slot) { slot = m; filed = true; break; }
+    if (!filed) {
+        if (m->comm) (void)rccl()->CommDestroy(m->comm);
+        delete m;
+        c->err = "gsx_comm_init: more than 8 live communicators on one context";
+        return GSX_E_STATE;
+    }
     *out = m;
     return GSX_OK;
 }
 
 int gsx_comm_destroy(gsx_comm* m) {
     if (!m) return GSX_E_INVALID;
-    if (m->comm) {
-        (void)hipSetDevice(m->ctx->device);
-        if (m->ctx->comm_stream) (void)hipStreamSynchronize(m->ctx->comm_stream);
-        (void)hipStreamSynchronize(m->ctx->stream);
-        (void)rccl()->CommDestroy(m->comm);
+    if (m->ctx) {                  // (null: the context went first and gsx_destroy has already drained and released the communicator)
+        gsx_ctx* c = m->ctx;
+        if (m->comm) {
+            (void)hipSetDevice(c->device);
+            if (c->comm_stream) (void)hipStreamSynchronize(c->comm_stream);
+            (void)hipStreamSynchronize(c->stream);
+            (void)rccl()->CommDestroy(m->comm);
+        }
+        for (auto& slot : c->comms)
+            if (slot == m) slot = nullptr;
     }
     delete m;
     return GSX_OK;
+}
+
+// gsx_destroy: communicators that outlive their context are drained and detached here; their handles stay valid for
+// gsx_comm_destroy (which then only frees them) and are rejected by gsx_gather (ctx mismatch).
+extern "C++" void gsx_comm_detach_all(gsx_ctx* c) {
+    for (auto& slot : c->comms) {
+        if (!slot) continue;
+        if (slot->comm) {
+            if (c->comm_stream) (void)hipStreamSynchronize(c->comm_stream);
+            (void)rccl()->CommDestroy(slot->comm);
+            slot->comm = nullptr;
+        }
+        slot->ctx = nullptr;
+        slot = nullptr;
+    }
 }
 
 int gsx_gather(gsx_ctx* c, gsx_comm* m, const void* send_dev, uint64_t send_bytes, void* recv_dev, const uint64_t* recv_offsets,

@@ -309,6 +309,7 @@ struct gsx_ctx : GsxFrameSlot {
         bool pending = false;            // recorded and not yet known to have completed
     } gathers[GSX_GATHER_RING];
     uint32_t gather_pos = 0;
+    struct gsx_comm* comms[8] = {};       // live communicators of this context (gsx_comm_init files them, gsx_destroy detaches them)
 
     // timing
     hipEvent_t ev[40] = {};
@@ -379,5 +380,6 @@ int gsx_frame_finish(gsx_ctx* c);                // waits for every queued frame
 int gsx_frame_finish_active(gsx_ctx* c);         // the same for the active slot's frame only
 int gsx_frame_finish_touching(gsx_ctx* c, const uint8_t* lo, const uint8_t* hi);   // only the queued frames that render into [lo, hi)
 int gsx_comm_guard(gsx_ctx* c, hipStream_t st, const uint8_t* lo, const uint8_t* hi);   // st waits for the exchanges that still use [lo, hi)
+void gsx_comm_detach_all(gsx_ctx* c);           // gsx_destroy: drains and releases the communicators that are still alive
 int gsx_comm_join(gsx_ctx* c);                   // main stream waits for every exchange queued so far (no host wait)
 void gsx_slot_switch(gsx_ctx* c);                // the other frame slot becomes the active one

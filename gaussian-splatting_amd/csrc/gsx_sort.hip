@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 
 // ---------------------------------------------------------------------------
 // Upload: 80-B AoS `Splat` (Splat.h:19-29) -> SoA positions (key pass) + 64-B AoS records (frame loop).
@@ -439,20 +440,24 @@ static __device__ __align__(256) unsigned char scratch[GSX_NOALLOC_SCRATCH_BYTES
 
 #define GSX_MAX_DEVICES 64
 static unsigned char* g_scratch_ptr[GSX_MAX_DEVICES] = {};   // per device: each GPU holds its own copy at its own address
+static std::once_flag g_scratch_once[GSX_MAX_DEVICES];        // two host threads may create contexts on one device at the same time
+static hipError_t g_scratch_err[GSX_MAX_DEVICES] = {};
 
 // Called by gsx_create with `device` current.
 int gsx_scratch_init(gsx_ctx* c, int device) {
-    if (device < 0 || device >= GSX_MAX_DEVICES) return GSX_OK;   // (gsx_sort_noalloc reports it)
-    if (g_scratch_ptr[device]) return GSX_OK;
-    void* p = nullptr;
-    GSX_HIP(c, hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
-    g_scratch_ptr[device] = static_cast<unsigned char*>(p);
+    if (device < 0 || device >= GSX_MAX_DEVICES) return GSX_OK;   // (everything else works there; gsx_sort_noalloc says GSX_E_STATE with the reason)
+    std::call_once(g_scratch_once[device], [device] {
+        void* p = nullptr;
+        g_scratch_err[device] = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (g_scratch_err[device] == hipSuccess) g_scratch_ptr[device] = static_cast<unsigned char*>(p);
+    });
+    GSX_HIP(c, g_scratch_err[device]);
     return GSX_OK;
 }
 
 int gsx_launch_sort_noalloc(gsx_ctx* c, uint32_t* idx_out_dev) {
     if (c->device < 0 || c->device >= GSX_MAX_DEVICES || !g_scratch_ptr[c->device]) {
-        c->err = "gsx_sort_noalloc: no scratch address for this device";
+        c->err = "gsx_sort_noalloc: no scratch address for device " + std::to_string(c->device) + " (the table covers devices 0.." + std::to_string(GSX_MAX_DEVICES - 1) + ")";
         return GSX_E_STATE;
     }
     if (c->m_cap > GSX_NOALLOC_MAX_KEYS) {

@@ -7,6 +7,13 @@
 #include <cmath>
 #include <cstdint>
 
+// GSX_FACADE_WITH_GLM: the caller's code keeps its glm types (the reference passes glm::vec3 to SplatMesh::sortSplats,
+// SplatMesh.h:84-85, and fills a glm::mat4x4 Uniforms block from the camera, main.cpp:48-58,222-224): vec3 / vec4 / mat4
+// then convert to and from their glm counterparts implicitly.  Needs <glm/glm.hpp> on the include path (the reference's own).
+#if defined(GSX_FACADE_WITH_GLM)
+#include <glm/glm.hpp>
+#endif
+
 namespace gsx {
 
 struct vec3 {
@@ -14,6 +21,10 @@ struct vec3 {
     vec3() = default;
     vec3(float a, float b, float c) : x(a), y(b), z(c) {}
     explicit vec3(float s) : x(s), y(s), z(s) {}
+#if defined(GSX_FACADE_WITH_GLM)
+    vec3(const glm::vec3& v) : x(v.x), y(v.y), z(v.z) {}
+    operator glm::vec3() const { return glm::vec3(x, y, z); }
+#endif
     float& operator[](int i) { return (&x)[i]; }
     const float& operator[](int i) const { return (&x)[i]; }
 };
@@ -33,6 +44,10 @@ struct vec4 {
     vec4(float a, float b, float c, float d) : x(a), y(b), z(c), w(d) {}
     vec4(vec3 v, float d) : x(v.x), y(v.y), z(v.z), w(d) {}
     explicit vec4(float s) : x(s), y(s), z(s), w(s) {}
+#if defined(GSX_FACADE_WITH_GLM)
+    vec4(const glm::vec4& v) : x(v.x), y(v.y), z(v.z), w(v.w) {}
+    operator glm::vec4() const { return glm::vec4(x, y, z, w); }
+#endif
     float& operator[](int i) { return (&x)[i]; }
     const float& operator[](int i) const { return (&x)[i]; }
 };
@@ -76,6 +91,10 @@ struct mat4 {
     }
     vec4& operator[](int i) { return c[i]; }
     const vec4& operator[](int i) const { return c[i]; }
+#if defined(GSX_FACADE_WITH_GLM)
+    mat4(const glm::mat4& m) { for (int j = 0; j < 4; ++j) c[j] = vec4(m[j]); }
+    operator glm::mat4() const { return glm::mat4(glm::vec4(c[0]), glm::vec4(c[1]), glm::vec4(c[2]), glm::vec4(c[3])); }
+#endif
     const float* data() const { return &c[0].x; }
     float* data() { return &c[0].x; }
 };

@@ -189,8 +189,12 @@ class GsxFrameGather:
             self._start(self.next_batch % 2)
             self.next_batch += 1
 
-    def finish(self):
-        while self.next_batch * self.batch_frames < self.queued:
+    def finish(self, total_batches=None):
+        """Posts what is left.  EVERY rank must post the same number of exchanges (a grouped receive for a peer that never
+        sends never completes): when the ranks render different numbers of frames - views that do not divide evenly - pass
+        the collective batch count (the maximum over ranks of ceil(frames / batch_frames), e.g. an all-reduce MAX over the
+        control group); a rank that is short posts its last buffers again (stale slots, same sizes)."""
+        while self.next_batch * self.batch_frames < self.queued or (total_batches is not None and self.next_batch < total_batches):
             self._start(self.next_batch % 2)
             self.next_batch += 1
 

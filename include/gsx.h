@@ -131,7 +131,8 @@ int gsx_get_sort_samples(gsx_ctx* ctx, double* sum_ms, uint32_t* sorts, int rese
  *                   switches off the merged schedule: with a steady camera and few pairs behind the first window in the
  *                   last frame, the default takes everything behind that window in one iteration)
  *   "no_history"    1 = always pre-queue iterations for the whole selection (default: only as many ranks as
- *                   the last 8 frames needed before every tile was saturated, +25 %; the rest runs on demand)
+ *                   the last 8 frames needed before every tile was saturated, plus 12.5 % and a quarter of that depth again
+ *                   (2 K .. 32 K ranks); the rest runs on demand)
  *   "sort_algo"     form of the depth sort: 0 = automatic (default: two passes over HBM -- a partition on the top <= 13 key bits, then
  *                   every bucket finished inside LDS -- for selections of 2^17 .. ~2.4e7 splats whose key range is wide enough;
  *                   the three 9-bit LSD radix passes otherwise, and for some frames after a sort that found most keys in
@@ -261,6 +262,8 @@ typedef struct gsx_comm gsx_comm;
 int gsx_comm_unique_id(void* id128_out);
 /* Collective over the nranks processes: returns when all have joined.  nranks == 1 needs no id and no RCCL. */
 int gsx_comm_init(gsx_ctx* ctx, const void* id128, int rank, int nranks, gsx_comm** out);
+/* Destroy a communicator before its context.  A context destroyed first drains and releases the communicators it still
+ * has (their handles stay valid for gsx_comm_destroy, which then only frees them; gsx_gather rejects them). */
 int gsx_comm_destroy(gsx_comm* comm);
 /* Every rank contributes send_bytes bytes at send_dev; on `root`, rank r's bytes land at recv_dev + recv_offsets[r]
  * (recv_bytes[r] of them; recv_bytes[r] must equal what rank r sends, recv_bytes[root] the root's own send_bytes).
@@ -272,7 +275,10 @@ int gsx_comm_destroy(gsx_comm* comm);
  * never waits — and (b), if gsx_get_stream has been called since the last exchange, everything on that stream at the time of the call.  A frame rendered later into memory
  * an exchange still uses waits for it on the device.  The exchange is complete after gsx_sync, or behind any later
  * gsx_get_stream; exchanges of one context run one after another in call order (every rank must post them in the same
- * order).  The memory must stay valid until then. */
+ * order).  The memory must stay valid until then.
+ * EVERY rank must post the SAME NUMBER of exchanges: the root's grouped receive for a peer that never sends (or a peer's send
+ * the root never receives) never completes, and the next gsx_sync hangs with it.  When views do not divide evenly over the
+ * ranks, the short ranks post their last buffer again (multigpu.GsxFrameGather.finish takes the collective batch count). */
 int gsx_gather(gsx_ctx* ctx, gsx_comm* comm, const void* send_dev, uint64_t send_bytes, void* recv_dev,
                const uint64_t* recv_offsets, const uint64_t* recv_bytes, int root);
 

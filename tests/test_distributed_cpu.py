@@ -185,6 +185,11 @@ def test_frame_gather_posts_exchanges_late_and_in_order(pkg):
                     assert recv is None and off is None
             fg.finish()                                      # idempotent
             assert len(g.calls) == n_batches
+            # a rank that renders fewer frames than the longest one posts up to the collective batch count (same sizes,
+            # alternating buffers), so that every rank posts the same number of exchanges
+            fg.finish(total_batches=n_batches + 2)
+            assert len(g.calls) == n_batches + 2
+            assert [c[0] for c in g.calls[-2:]] == [fg.batches[n_batches % 2], fg.batches[(n_batches + 1) % 2]]
 
 
 def test_two_rank_gloo_view_and_band_sharding(tmp_path):

@@ -223,6 +223,30 @@ def test_octree_select_golden(gsx, oracle):
             assert np.array_equal(perm, oracle.sort_contract(g["oc_splats"], cam, ref_cut))
 
 
+def test_cut_without_count_then_sort_with_download(gsx_fresh, oracle):
+    """A cut queued without asking for its size (it runs on the sort stream) followed at once by a sort that downloads the
+    permutation: the size read back must be this cut's, not the previous one's."""
+    gsx = gsx_fresh
+    g = golden("lod.npz")
+    fc, nc = g["oc_first_child"], g["oc_n_children"]
+    gsx.upload(g["oc_splats"])
+    gsx.set_lod_octree(g["oc_center3"], g["oc_half3"], _octree_parent(fc, nc), (nc == 0).astype(np.uint8))
+    sizes = set()
+    for rep in range(3):
+        for p in range(3):
+            cam = g["pose_world"][p][12:15]
+            for t, thr in enumerate(g["oc_thr"]):
+                ref_cut = g[f"oc_cut_p{p}_t{t}"]
+                sizes.add(len(ref_cut))
+                gsx.select_octree(g["pose_viewproj"][p], float(thr), want_count=False)
+                perm = gsx.sort(cam)
+                assert len(perm) == len(ref_cut)
+                assert np.array_equal(perm, oracle.sort_contract(g["oc_splats"], cam, ref_cut))
+                dev, m = gsx.sorted_dev()
+                assert m == len(ref_cut)
+    assert len(sizes) > 1
+
+
 def _hc_parent(child2, n):
     parent = np.full(n, 0xFFFFFFFF, np.uint32)
     c = child2.reshape(-1, 2)

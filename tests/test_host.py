@@ -262,3 +262,18 @@ def test_gridhc_build_matches_live_reference(pkg, oracle, reference, synth):
         assert np.array_equal(t.cut_depth(d), reference.gridhc_get_indices_error(ref["handle"], d))
     reference.release(ref["handle"])
     t.close()
+
+
+def test_facade_compiles_with_the_callers_glm(tmp_path):
+    """GSX_FACADE_WITH_GLM: the caller keeps glm::vec3 / glm::mat4x4 (SplatMesh.h:84-85, main.cpp:48-58,222-224); compiled
+    against the reference's vendored glm when the checkout is present (the GPU box has none: skipped there)."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not os.path.exists("/root/reference/glm/glm.hpp"):
+        pytest.skip("no glm headers (reference checkout absent)")
+    exe = tmp_path / "glm_switch_test"
+    pkg_dir = os.path.join(root, "gaussian-splatting_amd")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(pkg_dir, "host"), "-I", os.path.join(root, "include"), "-I", "/root/reference",
+                           os.path.join(root, "tests", "cpp", "glm_switch_test.cpp"), "-o", str(exe), "-L", pkg_dir, "-lgsx", f"-Wl,-rpath,{pkg_dir}"])
+    assert subprocess.run([str(exe)], capture_output=True).returncode == 0
