@@ -19,8 +19,8 @@ N > 1, two shardings over a replicated splat set:
       goes to rank 0 in ONE gsx_gather (grouped RCCL send / recv on the library's exchange stream, beside the frames of the next batch)
       inside the timed region.
   --shard bands (strong scaling, BASELINE.json configs[4]): ONE 3840x2160 frame of the overlap-stress scene per step;
-      rank r sorts the (replicated) scene and renders tile band r, the bands are gathered in place into rank 0's
-      frame, and after the timed region rank 0 checks that frame byte for byte against the frame it renders alone.
+      rank r sorts the (replicated) scene -- with --band-cull only the splats whose quad can reach its band (gsx_select_band, a
+      conservative cull BEFORE the sort) -- and renders tile band r, the bands are gathered in place into rank 0's frame, and after the timed region rank 0 checks that frame byte for byte against the frame it renders alone.
   --gather torch falls back to torch.distributed.gather; it is also used, and reported, if gsx_gather's start-up
   self-check fails.
 
@@ -183,6 +183,10 @@ def main():
                          "the next frames anyway, and a short run then ends with one frame's transfer exposed instead of a batch's), "
                          "8 for the torch.distributed fallback (main-stream gathers)")
     ap.add_argument("--static-view", action="store_true", help="render the SAME pose every step (a camera at rest) instead of a new orbit pose per step")
+    ap.add_argument("--band-cull", action="store_true",
+                    help="bands: every rank first selects the splats whose quad can reach its band (gsx_select_band) and sorts only those; "
+                         "measured per rank on cfg 5 it is time-neutral (0.22-0.28 ms per band either way, tools/configs_table.py cfg5: the splats of "
+                         "that scene span 2-3 bands each and the sort runs beside the frame on its own stream), so the default sorts the replicated scene")
     ap.add_argument("--no-extras", action="store_true", help="skip the no-history / orbit / stage measurements after the timed region")
     ap.add_argument("--opt", action="append", default=[], help="name=value for gsx_set_option (A/B runs; not used by the driver)")
     a = ap.parse_args()
@@ -344,6 +348,8 @@ def main():
         pos = my_view[2] if pose is None else pose
         uni = u_mine if uniforms is None else uniforms
         last_pose[0] = (pos, uni)
+        if bands_mode and y1 > y0 and a.band_cull and world > 1:      # (one rank = one band = the whole frame: nothing to cull)
+            g.select_band(uni, W, H, y0, y1, want_count=False)     # cull by band BEFORE the sort: on the sort stream, no host wait
         g.sort(pos, download=False)          # queued behind the running frame
         if bands_mode:
             if exchange and gather_kind == "gsx":
@@ -452,6 +458,7 @@ def main():
             gathered = mg.compose_bands(band_recv, bands, W).cpu().numpy()
         else:
             hip.hipMemcpy(C.c_void_p(gathered.ctypes.data), C.c_void_p(band_last[0] or g.framebuffer_dev()[0]), C.c_size_t(fb_bytes), C.c_int(2))
+        g.select_all()
         g.sort(last_pose[0][0], download=False)
         alone = g.render(last_pose[0][1], W, H).reshape(-1)
         bands_match = bool(np.array_equal(gathered, alone)) if (world == 1 or gather_kind != "none") else None

@@ -22,7 +22,7 @@ GSX_OK, GSX_E_INVALID, GSX_E_HIP, GSX_E_NOMEM, GSX_E_STATE, GSX_E_UNSUPPORTED, G
 ABI_SYMBOLS = [
     "gsx_create", "gsx_destroy", "gsx_last_error", "gsx_sync", "gsx_set_profiling", "gsx_get_timings", "gsx_get_scatter_samples", "gsx_get_sort_samples", "gsx_set_option",
     "gsx_upload_splats", "gsx_upload_splats_dev", "gsx_select_all", "gsx_select_list", "gsx_set_lod_octree",
-    "gsx_set_lod_hc", "gsx_select_octree", "gsx_select_hc", "gsx_get_selection", "gsx_sort", "gsx_sort_noalloc", "gsx_get_sorted_dev",
+    "gsx_set_lod_hc", "gsx_select_octree", "gsx_select_hc", "gsx_select_band", "gsx_get_selection", "gsx_sort", "gsx_sort_noalloc", "gsx_get_sorted_dev",
     "gsx_get_keys", "gsx_render", "gsx_get_framebuffer_dev", "gsx_set_framebuffer_dev", "gsx_get_stream",
     "gsx_comm_unique_id", "gsx_comm_init", "gsx_comm_destroy", "gsx_gather",
     "gsx_host_convert_raw", "gsx_host_load_splat_file", "gsx_host_free", "gsx_host_load_ply_raw", "gsx_host_load_ply_file", "gsx_host_camera", "gsx_host_orbit_pose",
@@ -160,6 +160,13 @@ class Gsx:
         cam = np.ascontiguousarray(cam_pos, np.float32)
         m = C.c_uint32(0)
         self._chk(self.lib.gsx_select_hc(self.ctx, _ptr(cam), C.c_float(threshold), C.byref(m) if want_count else None))
+        return m.value
+
+    def select_band(self, uniforms, width, height, y0, y1, want_count=True):
+        """gsx_select_band: the splats whose quad can reach rows [y0, y1) (tile-band sharding)."""
+        m = C.c_uint32(0)
+        self._chk(self.lib.gsx_select_band(self.ctx, C.byref(uniforms), C.c_uint32(width), C.c_uint32(height), C.c_uint32(y0), C.c_uint32(y1),
+                                           C.byref(m) if want_count else None))
         return m.value
 
     def selection(self):

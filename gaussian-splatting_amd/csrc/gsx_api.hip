@@ -597,6 +597,26 @@ int gsx_select_hc(gsx_ctx* c, const float cam_pos[3], float threshold, uint32_t*
     return finish_select(c, m_out);
 }
 
+int gsx_select_band(gsx_ctx* c, const gsx_uniforms* u, uint32_t width, uint32_t height, uint32_t y0, uint32_t y1, uint32_t* m_out) {
+    if (!c || !u || width == 0 || height == 0 || y0 >= y1 || y1 > height) return GSX_E_INVALID;
+    int rc = set_device(c);
+    if (rc) return rc;
+    float wt[16];      // view * model, glm's operation order (glm/detail/type_mat4x4.inl:630-648)
+    for (int j = 0; j < 4; ++j)
+        for (int i = 0; i < 4; ++i) {
+            float t = u->viewMatrix[0 * 4 + i] * u->modelMatrix[j * 4 + 0];
+            t = t + u->viewMatrix[1 * 4 + i] * u->modelMatrix[j * 4 + 1];
+            t = t + u->viewMatrix[2 * 4 + i] * u->modelMatrix[j * 4 + 2];
+            t = t + u->viewMatrix[3 * 4 + i] * u->modelMatrix[j * 4 + 3];
+            wt[j * 4 + i] = t;
+        }
+    if ((rc = begin_select(c))) return rc;
+    if ((rc = gsx_launch_select_band(c, wt, u->projectionMatrix, u->cutOff * u->splatSize, height, y0, y1))) { c->sel_stream = c->stream; return rc; }
+    rc = finish_select(c, m_out);
+    c->m_cap = m_out ? *m_out : static_cast<uint32_t>(c->n);      // (finish_select assumes an LOD tree's node count)
+    return rc;
+}
+
 int gsx_get_selection(gsx_ctx* c, uint32_t* idx_out, uint32_t capacity, uint32_t* m_out) {
     if (!c || !m_out) return GSX_E_INVALID;
     int rc = set_device(c);

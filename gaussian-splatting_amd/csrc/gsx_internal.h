@@ -372,6 +372,7 @@ int gsx_launch_sort_noalloc(gsx_ctx* c, uint32_t* idx_out_dev);   // the same so
 int gsx_launch_keys_only(gsx_ctx* c, float* dist_dev);
 int gsx_launch_select_octree(gsx_ctx* c, const float vp[16], float thr);
 int gsx_launch_select_hc(gsx_ctx* c, const float cam[3], float thr);
+int gsx_launch_select_band(gsx_ctx* c, const float wt[16], const float proj[16], float cut_s, uint32_t height, uint32_t y0, uint32_t y1);
 int gsx_launch_sort_list(gsx_ctx* c, uint32_t m); // ascending re-order of an explicit index list
 int gsx_launch_render(gsx_ctx* c, const gsx_uniforms* u, uint32_t w, uint32_t h, uint32_t y0, uint32_t y1);
 void gsx_sample_drain(gsx_ctx* c, uint32_t slot);   // folds a finished level-2 sample into samp_sum_ms / samp_n

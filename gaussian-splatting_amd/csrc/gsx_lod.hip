@@ -16,6 +16,7 @@
 // the reference's.  The reference emits BFS/queue order; the sort's tie rule
 // needs ascending ids, which is what compaction yields.
 #include "gsx_internal.h"
+#include <cmath>
 #include "gsx_radix.hpp"
 
 struct GsxMat4 { float m[16]; };
@@ -324,4 +325,69 @@ int gsx_launch_sort_list(gsx_ctx* c, uint32_t m) {
         hipLaunchKernelGGL(k_mark_list, dim3(gsx_div_up(m, 256)), dim3(256), 0, c->sel_stream, c->vals[0], m, n, c->lod_emit,
                            c->flags);
     return compact(c, n);
+}
+
+// ---------------------------------------------------------------------------
+// Cull-by-band selection (tile-band sharding): the splats whose quad can reach rows [y0, y1) of the frame.
+// Conservative, from the 16-byte SoA record alone (position + radius, coalesced): the quad's half extent in view space is at
+// most cutOff * splatSize * ||W||_F * radius per axis vector (W = the 3x3 of view * model), two axis vectors, projected with
+// row 1 of the projection.  A splat the rasterizer would draw into the band is never dropped; what is kept and lies
+// outside is dropped later by the exact projection (k_chunk_count).  Flags -> ascending ids like the LOD cuts, so the
+// band's sorted permutation is the full permutation with the culled entries removed.
+// ---------------------------------------------------------------------------
+struct GsxBandView { float wt[16], proj[16]; float reach /* cutOff * splatSize * ||W||_2 */, height, y0, y1; };
+__global__ __launch_bounds__(256) void k_band_flags(const float4* __restrict__ pos4, uint32_t n, GsxBandView v, uint8_t* __restrict__ emit) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 p = pos4[i];
+    float c[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) c[r] = (v.wt[r] * p.x + v.wt[4 + r] * p.y) + (v.wt[8 + r] * p.z + v.wt[12 + r]);
+    const float w = v.proj[11] * c[2] + v.proj[15] * c[3];
+    const float ccy = (v.proj[1] * c[0] + v.proj[5] * c[1]) + (v.proj[9] * c[2] + v.proj[13] * c[3]);
+    const float iw = 1.0f / w, hh = 0.5f * v.height;
+    const float cy = (0.5f - ccy * iw * 0.5f) * v.height;
+    // the quad's two axis vectors are orthogonal in the view plane with lengths <= reach * radius: their y parts sum to <= sqrt(2) x that
+    const float ey = 1.41422f * v.reach * p.w * (fabsf(v.proj[1]) + fabsf(v.proj[5])) * iw * hh * 1.001f + 1.0f;
+    // (written so that anything not finite, and anything at or behind the camera plane, is KEPT: the exact test decides)
+    const bool cull = (w > 1.0e-6f) && (cy + ey < v.y0 || cy - ey >= v.y1);
+    emit[i] = cull ? 0 : 1;
+}
+
+int gsx_launch_select_band(gsx_ctx* c, const float wt[16], const float proj[16], float cut_s, uint32_t height, uint32_t y0, uint32_t y1) {
+    const uint32_t n = static_cast<uint32_t>(c->n);
+    GsxBandView v;
+    float fro = 0.0f;
+    for (int k = 0; k < 16; ++k) { v.wt[k] = wt[k]; v.proj[k] = proj[k]; }
+    for (int col = 0; col < 3; ++col)
+        for (int r = 0; r < 3; ++r) fro += wt[col * 4 + r] * wt[col * 4 + r];
+    // spectral norm of the 3x3 of view * model: power iteration on W^T W (converges from below: 1 % margin, never above Frobenius)
+    double g[3][3], x[3] = {0.577, 0.577, 0.577}, lam = 0.0;
+    for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b) {
+            g[a][b] = 0.0;
+            for (int r = 0; r < 3; ++r) g[a][b] += static_cast<double>(wt[a * 4 + r]) * wt[b * 4 + r];
+        }
+    for (int it = 0; it < 64; ++it) {
+        double y[3] = {0, 0, 0}, nrm = 0.0;
+        for (int a = 0; a < 3; ++a)
+            for (int b = 0; b < 3; ++b) y[a] += g[a][b] * x[b];
+        for (int a = 0; a < 3; ++a) nrm += y[a] * y[a];
+        nrm = std::sqrt(nrm);
+        if (!(nrm > 0.0)) break;
+        lam = nrm;
+        for (int a = 0; a < 3; ++a) x[a] = y[a] / nrm;
+    }
+    double w2 = std::sqrt(lam) * 1.01;
+    if (!(w2 > 0.0) || w2 > std::sqrt(static_cast<double>(fro))) w2 = std::sqrt(static_cast<double>(fro));
+    v.reach = cut_s * static_cast<float>(w2) * 1.0001f;
+    v.height = static_cast<float>(height);
+    v.y0 = static_cast<float>(y0);
+    v.y1 = static_cast<float>(y1);
+    if (c->profiling) GSX_HIP(c, hipEventRecord(c->ev[EV_SEL0], c->sel_stream));
+    c->lod_stamp = 255u;            // the flags below overwrite the octree cut's stamps
+    if (n) hipLaunchKernelGGL(k_band_flags, dim3(gsx_div_up(n, 256)), dim3(256), 0, c->sel_stream, c->pos4, n, v, c->lod_emit);
+    const int rc = compact(c, n);
+    if (c->profiling) GSX_HIP(c, hipEventRecord(c->ev[EV_SEL1], c->sel_stream));
+    return rc;
 }

@@ -23,7 +23,30 @@ __global__ __launch_bounds__(256) void k_upload_soa(const float4* __restrict__ a
     if (i >= n) return;
     const float4 c0 = aos[i * 5 + 0], c1 = aos[i * 5 + 1], c2 = aos[i * 5 + 2];
     const float4 pos = aos[i * 5 + 3];
-    pos4[i] = pos;
+    // SoA record of the key pass: position + a conservative radius for the cull-by-band selection: the square root of the
+    // covariance's largest eigenvalue (closed form for a symmetric 3x3, a little margin; the trace where that breaks down).
+    // The 64-B record below keeps transform[3] as it is.
+    float rho;
+    {
+        const float s00 = c0.x, s11 = c1.y, s22 = c2.z, s01 = c1.x, s02 = c2.x, s12 = c2.y;
+        const float tr = s00 + s11 + s22;
+        float lmax = tr;
+        const float p1 = s01 * s01 + s02 * s02 + s12 * s12, q = tr * (1.0f / 3.0f);
+        const float d0 = s00 - q, d1 = s11 - q, d2 = s22 - q;
+        const float p2 = d0 * d0 + d1 * d1 + d2 * d2 + 2.0f * p1;
+        if (p2 > 0.0f) {
+            const float pp = sqrtf(p2 * (1.0f / 6.0f)), ip = 1.0f / pp;
+            const float b00 = d0 * ip, b11 = d1 * ip, b22 = d2 * ip, b01 = s01 * ip, b02 = s02 * ip, b12 = s12 * ip;
+            float r = 0.5f * (b00 * (b11 * b22 - b12 * b12) - b01 * (b01 * b22 - b12 * b02) + b02 * (b01 * b12 - b11 * b02));
+            r = fminf(fmaxf(r, -1.0f), 1.0f);
+            const float lam = q + 2.0f * pp * cosf(acosf(r) * (1.0f / 3.0f));
+            if (lam >= 0.0f && lam <= tr) lmax = fminf(tr, lam * 1.002f + 1.0e-12f);
+        } else if (p2 == 0.0f) {
+            lmax = fmaxf(q, 0.0f);
+        }
+        rho = (lmax >= 0.0f && lmax < 3.0e38f) ? sqrtf(lmax) * 1.0001f : __builtin_huge_valf();
+    }
+    pos4[i] = make_float4(pos.x, pos.y, pos.z, rho);
     // column-major: c0 = (s00,s10,s20,_), c1 = (s01,s11,s21,_), c2 = (s02,s12,s22,_)
     float4* g = reinterpret_cast<float4*>(geo + i);
     g[0] = pos;

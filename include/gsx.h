@@ -183,6 +183,13 @@ int gsx_select_octree(gsx_ctx* ctx, const float viewproj[16], float min_screen_a
 /* HC::get_indices / GridHC::get_indices(camera, threshold, w) (HC.cpp:100-132,
  * GridHC.cpp:94-111). */
 int gsx_select_hc(gsx_ctx* ctx, const float cam_pos[3], float threshold, uint32_t* m_out);
+/* Tile-band sharding (no counterpart in the reference, which draws one frame on one GPU): selects the splats
+ * whose quad can reach rows [y0, y1) of a width x height frame drawn with these uniforms -- a conservative test on the
+ * splat's position and a radius kept beside it, so nothing the rasterizer would draw into the band is dropped -- for a rank
+ * that renders only that band (gsx_render's y0 / y1).  gsx_sort then orders just those: its permutation is the full
+ * permutation with the culled entries removed, and the band's pixels are the same bytes.  Selects from ALL uploaded splats
+ * (not from an LOD cut).  m_out may be NULL (no host sync). */
+int gsx_select_band(gsx_ctx* ctx, const gsx_uniforms* u, uint32_t width, uint32_t height, uint32_t y0, uint32_t y1, uint32_t* m_out);
 /* Copies the current selection (ascending ids) to the host. */
 int gsx_get_selection(gsx_ctx* ctx, uint32_t* idx_out_host, uint32_t capacity, uint32_t* m_out);
 

@@ -105,6 +105,38 @@ def test_render_tile_bands_compose(gsx, pkg, oracle, synth):
     assert np.array_equal(out, whole)
 
 
+def test_band_cull_before_the_sort(gsx_fresh, pkg, oracle, synth):
+    """Tile-band sharding with the cull BEFORE the sort: gsx_select_band keeps the splats whose quad can reach the
+    band's rows; the band's permutation is the full permutation with the culled entries removed, and the bands rendered from
+    their own culled selections compose to the bytes of the whole frame."""
+    gsx = gsx_fresh
+    w, h, n = 640, 368, 150_000
+    splats = oracle.raw_to_splat(synth.overlap_stress_cloud(n, seed=4))
+    view, proj, cam = camera(oracle, w, h, steps=2)
+    u = pkg.make_uniforms(proj, view)
+    gsx.upload(splats)
+    full = gsx.sort(cam)
+    whole = gsx.render(u, w, h)
+    assert whole[..., :3].std() > 5
+    out = np.zeros_like(whole)
+    kept = []
+    for y0, y1 in ((0, 46), (46, 92), (92, 138), (138, 184), (184, 230), (230, 276), (276, 322), (322, 368)):
+        for want in (True, False):
+            m = gsx.select_band(u, w, h, y0, y1, want_count=want)
+            ids = gsx.selection()
+            assert np.all(ids[1:] > ids[:-1]) and (not want or m == len(ids))
+            perm = gsx.sort(cam)
+            assert np.array_equal(perm, full[np.isin(full, ids)])          # the full order with the culled entries removed
+        gsx.render(u, w, h, y0, y1, out=out)
+        kept.append(len(ids))
+    assert np.array_equal(out, whole)
+    assert min(kept) < 0.6 * n and sum(kept) < 4 * n, kept                  # the cull does remove most of a band's splats
+    # back to everything: the whole frame again, same bytes
+    gsx.select_all()
+    assert np.array_equal(gsx.sort(cam), full)
+    assert np.array_equal(gsx.render(u, w, h), whole)
+
+
 @pytest.mark.parametrize("bayer,scale", [(10, 0.3), (2, 1.0), (4, 1.0)])
 def test_render_bayer_and_threshold_modes(gsx, pkg, oracle, synth, bayer, scale):
     w, h = 160, 120

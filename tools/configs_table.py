@@ -134,6 +134,27 @@ def cfg5():
                 dt = (time.perf_counter() - t0) / k
             out[name + "_ms"] = dt * 1e3
             out[name + "_tile_pairs_last_render"] = g.timings()["tile_pairs"]
+        # what ONE of 8 ranks does per frame (N = 8 rehearsed band by band on one GPU): sort + its band, with the scene sorted
+        # whole (replicated sort) or culled to the band first (gsx_select_band); the slowest band sets the frame time at N = 8
+        for name, cull in (("per_rank_replicated_sort", False), ("per_rank_band_cull", True)):
+            per = []
+            for (y0, y1) in bands:
+                for rnd in range(2):
+                    g.sync()
+                    t0 = time.perf_counter()
+                    k = 20
+                    for _ in range(k):
+                        if cull:
+                            g.select_band(u, W, H, y0, y1, want_count=False)
+                        g.sort(pos, download=False)
+                        g.render(u, W, H, y0=y0, y1=y1, download=False)
+                    g.sync()
+                    dt = (time.perf_counter() - t0) / k
+                per.append(dt * 1e3)
+                if cull:
+                    g.select_all()
+            out[name + "_ms_per_band"] = [round(x, 4) for x in per]
+            out[name + "_slowest_band_ms"] = max(per)
     emit({"config": "cfg5 (one GPU)", "splats": n, "width": W, "height": H, **out})
 
 
