@@ -475,24 +475,44 @@ def test_large_overlap_4k_bands(gsx_fresh, pkg, oracle, synth):
         assert np.array_equal(gsx.render(u, w, h), img)
 
 
-def test_20m_scene_properties(gsx_fresh, pkg, oracle, synth):
-    """cfg-4 size (20M splats): sort and frame loop at the largest configured scene, by properties."""
+def test_cfg4_all_64_poses_at_20m(gsx_fresh, pkg, oracle, synth):
+    """cfg 4 at its real shape: the 20 M-splat scene under all 64 poses of the pose set (8 azimuths x 8 elevations, what
+    bench.py --shard views deals out).  Every pose: the permutation is sorted by the oracle's keys, ties ascend by index,
+    every index appears once; every 8th pose: a full permutation check and frame determinism (two renders, same bytes);
+    one pose: the frame against the image oracle at 96 x 54 (the oracle projects all 20 M splats: ~25 s of CPU)."""
+    import importlib
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    bench = importlib.import_module("bench")
     gsx = gsx_fresh
     n, w, h = 20_000_000, 1920, 1080
     splats = oracle.raw_to_splat(synth.clustered_cloud(n, seed=20))
     gsx.upload(splats)
-    for steps in (0, 3):
-        view, proj, cam = camera(oracle, w, h, steps)
+    views = bench.orbit_views(pkg, 64, w, h)
+    total = n * (n - 1) // 2
+    forms = set()
+    for v, (view, proj, cam) in enumerate(views):
         perm = gsx.sort(cam)
+        forms.add(gsx.timings()["sort_form"])
+        assert len(perm) == n
         k = oracle.distance_keys(splats, cam)[perm]
-        assert np.all(k[:-1] >= k[1:])                                   # sortedness
+        assert np.all(k[:-1] >= k[1:]), v                                 # sortedness
         same = k[1:] == k[:-1]
-        assert np.all(perm[1:][same] > perm[:-1][same])                  # ties by ascending index
-        assert np.array_equal(np.bincount(perm, minlength=n), np.ones(n, np.int64))   # a permutation
-        u = pkg.make_uniforms(proj, view)
-        img = gsx.render(u, w, h)
-        assert np.all(img[..., 3] == 255) and img[..., :3].std() > 10
-        assert np.array_equal(gsx.render(u, w, h), img)
+        assert np.all(perm[1:][same] > perm[:-1][same]), v                # ties by ascending index
+        assert int(perm.sum(dtype=np.uint64)) == total, v                 # (cheap necessary condition of a permutation)
+        if v % 8 == 0:
+            assert np.array_equal(np.bincount(perm, minlength=n), np.ones(n, np.int64)), v
+            u = pkg.make_uniforms(proj, view)
+            img = gsx.render(u, w, h)
+            assert np.all(img[..., 3] == 255) and img[..., :3].std() > 10
+            assert np.array_equal(gsx.render(u, w, h), img), v
+    assert forms <= {1, 2}
+    view, proj, cam = views[5]
+    perm = gsx.sort(cam)
+    ws, hs = 96, 54
+    img = gsx.render(pkg.make_uniforms(proj, view), ws, hs)
+    check_image(img, oracle.render(splats, perm, orc.make_uniforms(proj, view), ws, hs))
     del splats
 
 
