@@ -245,6 +245,7 @@ struct gsx_ctx : GsxFrameSlot {
     struct Gsx2Stats* s2_stats_host = nullptr;   // pinned: bucket statistics of the latest two-pass sort (copied behind it)
     hipEvent_t ev_s2_stats = nullptr;
     bool s2_stats_rec = false;
+    uint32_t s2_stats_tick = 0;
     uint32_t s2_backoff = 0, s2_backoff_len = 0;   // sorts left on the LSD passes after a sort that sent many keys through k2_big / length of the next pause
     uint64_t opt_sort_algo = 0;                    // 0 automatic, 1 LSD passes only, 2 two-pass whenever its plan allows (any size)
     bool sort_two_pass = false;                    // the latest depth sort ran the two-pass form

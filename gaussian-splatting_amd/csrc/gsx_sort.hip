@@ -324,6 +324,7 @@ static int launch_sort_in(gsx_ctx* c, const GsxSortBuffers& sb, hipStream_t st) 
     if (profiling) GSX_HIP(c, hipEventRecord(c->ev[EV_KEY0], st));
     uint32_t cur = 0;
     uint32_t* result = sb.result;
+    bool want_stats = false;
     if (p2.ok) {
         const Gsx2Workspace w = gsx2_ws_carve(c->s2_ws, c->sort_cap);
         if (c->sel_iota)
@@ -347,17 +348,11 @@ static int launch_sort_in(gsx_ctx* c, const GsxSortBuffers& sb, hipStream_t st) 
         e0 = profiling ? c->ev[EV_X0 + 2] : samp_a[1];
         e1 = profiling ? c->ev[EV_X0 + 3] : samp_b[1];
         if (e0) GSX_HIP(c, hipEventRecord(e0, st));
-        // three instances by bucket size; the last one also sorts what does not fit LDS (through the scratch twin of the pairs)
+        // two instances by bucket size; the larger one also sorts what does not fit LDS (through the scratch twin of the pairs)
         hipLaunchKernelGGL((k2_local<GSX2_IPT>), dim3(p2.nd), dim3(GSX2_NT), 0, st, c->s2_pairs, c->s2_scratch, w.base, p2.nd, p2.map, p2.idx_bits, result);
-        hipLaunchKernelGGL((k2_local<16>), dim3(p2.nd), dim3(GSX2_NT), 0, st, c->s2_pairs, c->s2_scratch, w.base, p2.nd, p2.map, p2.idx_bits, result);
         hipLaunchKernelGGL((k2_local<8>), dim3(p2.nd), dim3(GSX2_NT), 0, st, c->s2_pairs, c->s2_scratch, w.base, p2.nd, p2.map, p2.idx_bits, result);
         if (e1) GSX_HIP(c, hipEventRecord(e1, st));
-        // bucket statistics for the next sorts' choice of form (read when the copy has landed, never waited for)
-        if (!c->s2_stats_rec) {
-            GSX_HIP(c, hipMemcpyAsync(c->s2_stats_host, w.stats, sizeof(Gsx2Stats), hipMemcpyDeviceToHost, st));
-            GSX_HIP(c, hipEventRecord(c->ev_s2_stats, st));
-            c->s2_stats_rec = true;
-        }
+        want_stats = true;
     } else {
     if (c->sel_iota)
         hipLaunchKernelGGL(k_keygen_hist0<true>, dim3(g), dim3(GSX_SORT_NT), 0, st, c->pos4, nullptr, c->m_dev, c->cam[0],
@@ -387,13 +382,21 @@ static int launch_sort_in(gsx_ctx* c, const GsxSortBuffers& sb, hipStream_t st) 
         hipLaunchKernelGGL(k_copy_gated, dim3(g), dim3(512), 0, st, &c->flags->wide_m, sb.vals[cur ^ 1], result);
     }
     if (sampled_pass == GSX_SAMPLE_WHOLE) GSX_HIP(c, hipEventRecord(samp_b[GSX_SAMPLE_WHOLE], st));
+    // bucket statistics of a two-pass sort for the next sorts' choice of form: every 4th sort, read when the copy has landed,
+    // never waited for (a 16-byte copy is a 4 us blit on the stream)
+    if (want_stats && !c->s2_stats_rec && (c->s2_stats_tick++ & 3u) == 0u) {
+        const Gsx2Workspace w = gsx2_ws_carve(c->s2_ws, c->sort_cap);
+        GSX_HIP(c, hipMemcpyAsync(c->s2_stats_host, w.stats, sizeof(Gsx2Stats), hipMemcpyDeviceToHost, st));
+        GSX_HIP(c, hipEventRecord(c->ev_s2_stats, st));
+        c->s2_stats_rec = true;
+    }
     if (profiling) GSX_HIP(c, hipEventRecord(c->ev[EV_SORT1], st));
     GSX_HIP(c, hipGetLastError());
     if (sb.with_events) {   // (the context's own sort: what gsx_get_timings reports)
         c->sort_passes = static_cast<uint32_t>(n_stage) + (gated ? 1u : 0u);   // (the gated pass counts as launched)
         c->sort_gated = gated;
         c->sort_two_pass = p2.ok;
-        c->sort_launches = p2.ok ? 6u : 3u * static_cast<uint32_t>(plan.n_passes) - 1u;   // (pass 0's count is fused into the key kernel)
+        c->sort_launches = p2.ok ? 5u : 3u * static_cast<uint32_t>(plan.n_passes) - 1u;   // (pass 0's count is fused into the key kernel)
     }
     return GSX_OK;
 }

@@ -33,7 +33,7 @@
 #define GSX2_MAX_COLS 2048
 #define GSX2_COLMAX 12288                // keys of a column at most (k2_partition stages them in LDS: 96 KB)
 #define GSX2_KPT (GSX2_COLMAX / GSX2_PNT)
-#define GSX2_CAP 12288                   // pairs of the largest bucket k2_local sorts in LDS
+#define GSX2_CAP 9216                    // pairs of the largest bucket k2_local sorts in LDS
 #define GSX2_IPT (GSX2_CAP / GSX2_NT)
 #define GSX2_MAX_Q 13                    // bits of k2_local's bins at most (2^13 packed 16-bit bins = 16 KB)
 
@@ -267,21 +267,22 @@ __global__ __launch_bounds__(GSX2_PNT) void k2_partition(const uint32_t* __restr
 }
 
 // ---- D: one bucket per workgroup, finished in LDS -----------------------------------------------------------------
-// Element word in LDS: (key bits below the bin << idx_bits) | index.  Three instances share the buckets by size, so that
+// Element word in LDS: (key bits below the bin << idx_bits) | index.  Two instances share the buckets by size, so that
 // the many ordinary buckets do not pay for the LDS of the largest: IPT = 8 (up to 4096 pairs, 32 KB: four workgroups per
-// CU), IPT = 16 (up to 8192, 48 KB: three per CU), and IPT = GSX2_IPT (up to GSX2_CAP; 64 KB), whose workgroups also take
-// what nothing sorts in LDS -- a larger bucket, or a coarse bucket near the camera whose key bits do not fit the word --
-// through gsx2_big_bucket (defined below).
+// CU) and IPT = GSX2_IPT = 18 (up to GSX2_CAP = 9216, 52 KB: still three per CU), whose workgroups also take what nothing sorts
+// in LDS -- a larger bucket, or a coarse bucket near the camera whose key bits do not fit the word -- through
+// gsx2_big_bucket (defined below).  (A third instance for 8192 .. 12288 pairs at 64 KB cost every sort a launch that
+// found nothing to do: 5 us.  9216 is what three workgroups per CU leave room for; the bench orbit's largest bucket is 8819.)
 __device__ __forceinline__ void gsx2_big_bucket(uint2* pairs, uint2* scratch, uint32_t b0, uint32_t size, uint32_t r, uint32_t idx_bits,
                                                 uint32_t* result, uint32_t* lds);
 
 template <int IPT>
-__global__ __launch_bounds__(GSX2_NT) __attribute__((amdgpu_waves_per_eu(IPT == 8 ? 8 : (IPT == 16 ? 6 : 4), IPT == 8 ? 8 : (IPT == 16 ? 6 : 4))))
+__global__ __launch_bounds__(GSX2_NT) __attribute__((amdgpu_waves_per_eu(IPT == 8 ? 8 : 6, IPT == 8 ? 8 : 6)))
 void k2_local(uint2* pairs, uint2* scratch, const uint32_t* __restrict__ base, uint32_t nd, Gsx2Map mp, uint32_t idx_bits,
               uint32_t* __restrict__ result) {
-    constexpr bool REST = IPT > 16;                  // the instance that also takes what does not fit LDS
+    constexpr bool REST = IPT > 8;                   // the instance that also takes what does not fit LDS
     constexpr int QMAX = GSX2_MAX_Q;
-    constexpr uint32_t LO = IPT == 8 ? 0u : (IPT == 16 ? 8u * GSX2_NT : 16u * GSX2_NT), HI = IPT * GSX2_NT;
+    constexpr uint32_t LO = IPT == 8 ? 0u : 8u * GSX2_NT, HI = IPT * GSX2_NT;
     __shared__ uint32_t s_bins[(1 << QMAX) / 2];    // packed 16-bit: counts, then exclusive starts
     __shared__ uint32_t s_comp[IPT * GSX2_NT];
     __shared__ uint32_t s_tmp[GSX2_NT / 64];

@@ -77,7 +77,6 @@ int main(int argc, char** argv) {
         CK(hipEventRecord(ev[3], st));
         hipLaunchKernelGGL((k2_local<GSX2_IPT>), dim3(plan.nd), dim3(GSX2_NT), 0, st, d_pairs, d_scratch, d_base, plan.nd, plan.map, plan.idx_bits, d_res);
         CK(hipEventRecord(ev[6], st));
-        hipLaunchKernelGGL((k2_local<16>), dim3(plan.nd), dim3(GSX2_NT), 0, st, d_pairs, d_scratch, d_base, plan.nd, plan.map, plan.idx_bits, d_res);
         CK(hipEventRecord(ev[4], st));
         hipLaunchKernelGGL((k2_local<8>), dim3(plan.nd), dim3(GSX2_NT), 0, st, d_pairs, d_scratch, d_base, plan.nd, plan.map, plan.idx_bits, d_res);
         CK(hipEventRecord(ev[5], st));
@@ -91,7 +90,7 @@ int main(int argc, char** argv) {
     auto med = [](std::vector<float> v) { std::sort(v.begin(), v.end()); return v[v.size() / 2] * 1e3f; };
     Gsx2Stats hs; CK(hipMemcpy(&hs, d_stats, sizeof hs, hipMemcpyDeviceToHost));
     GsxDevFlags hf; CK(hipMemcpy(&hf, d_flags, sizeof hf, hipMemcpyDeviceToHost));
-    printf("keygen+hist %.1f us  scan %.1f  partition %.1f  local: rest %.1f + mid %.1f + small %.1f  | whole %.1f us = %.2f G splats/s (92 B/splat: %.2f of 8 TB/s)\n", med(t[0]), med(t[1]),
+    printf("keygen+hist %.1f us  scan %.1f  partition %.1f  local: large %.1f (+%.1f) + small %.1f  | whole %.1f us = %.2f G splats/s (92 B/splat: %.2f of 8 TB/s)\n", med(t[0]), med(t[1]),
            med(t[2]), med(t[6]), med(t[3]) - med(t[6]), med(t[4]), med(t[5]), n / med(t[5]) * 1e-3, 92.0 * n / (med(t[5]) * 1e-6) / 8e12);
     printf("stats: big_buckets=%u big_keys=%u max_bucket=%u key_bound_flag=%u\n", hs.big_buckets, hs.big_keys, hs.max_bucket, hf.key_bound);
     std::vector<uint32_t> res(n);
