@@ -187,6 +187,7 @@ def main():
                     help="bands: every rank first selects the splats whose quad can reach its band (gsx_select_band) and sorts only those; "
                          "measured per rank on cfg 5 it is time-neutral (0.22-0.28 ms per band either way, tools/configs_table.py cfg5: the splats of "
                          "that scene span 2-3 bands each and the sort runs beside the frame on its own stream), so the default sorts the replicated scene")
+    ap.add_argument("--in-order", action="store_true", help="call order sort k, render k (no sort_ahead): the next sort is queued behind this frame's launches")
     ap.add_argument("--no-extras", action="store_true", help="skip the no-history / orbit / stage measurements after the timed region")
     ap.add_argument("--opt", action="append", default=[], help="name=value for gsx_set_option (A/B runs; not used by the driver)")
     a = ap.parse_args()
@@ -261,7 +262,7 @@ def main():
     for o in a.opt:
         k, v = o.split("=")
         g.set_option(k, int(v))
-    g.set_option("sample_every", 4 if a.steps < 40 else 8)     # (a short run still collects >= 6 launches and 2 whole sorts)
+    g.set_option("sample_every", int(os.environ.get("GSX_BENCH_SAMPLE_EVERY", 4 if a.steps < 40 else 8)))     # (a short run still collects >= 6 launches and 2 whole sorts)
     g.set_profiling(2)          # sampled sorts: alternately every HBM pass of the sort, and keys + sort as a whole, carry HIP events
     u_mine = pkg.make_uniforms(my_view[1], my_view[0])
     fb_bytes = W * H * 4
@@ -339,18 +340,36 @@ def main():
     pose_no = 0
     last_pose = [None]
 
+    # Sort ahead (library option sort_ahead): the step queues the sort of the NEXT pose, then this pose's frame, which draws the
+    # permutation its own pose was sorted for one step earlier.  Every step is still one sort and one frame of a new pose; what
+    # changes is that the next sort reaches the device before the host has worked through this frame's ~30 launches instead of
+    # after them (tools/host_vs_gpu.py: in call order sort, render, sort the device waited for the host between frames).
+    sort_ahead = not a.in_order and not (bands_mode and a.band_cull)
+    if sort_ahead:
+        g.set_option("sort_ahead", 1)
+    primed = [None]     # the pose whose permutation waits to be drawn
+
     def step(pose=None, uniforms=None):
         nonlocal frame_no, pose_no
+        nxt = None
         if pose is None and not a.static_view:
             k = (pose_no + pose_off) % len(path)
             pose, uniforms = path[k][2], path_unis[k]
             pose_no += 1
+            nxt = path[(pose_no + pose_off) % len(path)][2]
         pos = my_view[2] if pose is None else pose
         uni = u_mine if uniforms is None else uniforms
         last_pose[0] = (pos, uni)
-        if bands_mode and y1 > y0 and a.band_cull and world > 1:      # (one rank = one band = the whole frame: nothing to cull)
-            g.select_band(uni, W, H, y0, y1, want_count=False)     # cull by band BEFORE the sort: on the sort stream, no host wait
-        g.sort(pos, download=False)          # queued behind the running frame
+        if sort_ahead:
+            if primed[0] is not pos:                 # first step, or the caller left the orbit: forget what waits, sort this pose now
+                g.set_option("sort_ahead", 1)
+                g.sort(pos, download=False)
+            primed[0] = pos if nxt is None else nxt
+            g.sort(primed[0], download=False)        # the NEXT pose's sort, queued before this pose's frame
+        else:
+            if bands_mode and y1 > y0 and a.band_cull and world > 1:      # (one rank = one band = the whole frame: nothing to cull)
+                g.select_band(uni, W, H, y0, y1, want_count=False)     # cull by band BEFORE the sort: on the sort stream, no host wait
+            g.sort(pos, download=False)          # queued behind the running frame
         if bands_mode:
             if exchange and gather_kind == "gsx":
                 # Frames go round a ring of 4 framebuffers and the exchange of frame k is posted two frames late, just before
@@ -459,9 +478,25 @@ def main():
         else:
             hip.hipMemcpy(C.c_void_p(gathered.ctypes.data), C.c_void_p(band_last[0] or g.framebuffer_dev()[0]), C.c_size_t(fb_bytes), C.c_int(2))
         g.select_all()
+        g.set_option("sort_ahead", 0)                    # (forgets the permutation sorted ahead for a frame that never came)
+        primed[0] = None
         g.sort(last_pose[0][0], download=False)
         alone = g.render(last_pose[0][1], W, H).reshape(-1)
         bands_match = bool(np.array_equal(gathered, alone)) if (world == 1 or gather_kind != "none") else None
+    # ---- sort-ahead: the last frame of the timed region against the same pose rendered in call order (sort, then render) ----
+    ahead_match = None
+    if sort_ahead and rank == 0 and not bands_mode and a.steps > 0:
+        import ctypes as C
+        g.sync()
+        hip = C.CDLL("libamdhip64.so")
+        ptr = g.framebuffer_dev()[0]
+        timed_last = np.empty(fb_bytes, np.uint8)
+        hip.hipMemcpy(C.c_void_p(timed_last.ctypes.data), C.c_void_p(ptr), C.c_size_t(fb_bytes), C.c_int(2))
+        g.set_framebuffer_dev(None)
+        g.set_option("sort_ahead", 0)                    # (forgets the permutation sorted ahead for a frame that never came)
+        primed[0] = None
+        g.sort(last_pose[0][0], download=False)
+        ahead_match = bool(np.array_equal(timed_last, g.render(last_pose[0][1], W, H).reshape(-1)))
     fg = bg = None                                       # everything below is rank 0's alone: no collective
     exchange = False
 
@@ -574,6 +609,10 @@ def main():
                                                     "torch.distributed over gloo (host words: id broadcast, barrier, max of the elapsed times); pixels over RCCL")
         if bands_match is not None:
             out["bands_match_single_gpu_frame"] = bands_match
+        out["call_order"] = ("sort k+1, render k (library option sort_ahead: every frame draws the permutation sorted for its own pose one step earlier)"
+                             if sort_ahead else "sort k, render k")
+        if ahead_match is not None:
+            out["sort_ahead_last_frame_matches_in_order"] = ahead_match
         if sort_n_timed:
             out["sort_only_ms"] = sort_ms_timed
             out["sort_only_samples"] = sort_n_timed

@@ -2,6 +2,7 @@
 #include <cstddef>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <new>
 #include <vector>
 
@@ -103,12 +104,15 @@ int gsx_create(int device, gsx_ctx** out) {
     if (hipStreamCreateWithFlags(&c->parked.fstream, hipStreamNonBlocking) != hipSuccess) return fail(GSX_E_HIP);
     c->fstream = c->stream;              // slot 0 queues its frames on the main stream
     if (hipEventCreateWithFlags(&c->ev_sorted, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_pre, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_s2_stats, hipEventDisableTiming) != hipSuccess)
+        hipEventCreateWithFlags(&c->ev_s2_stats, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_sample_done, hipEventDisableTiming) != hipSuccess)
         return fail(GSX_E_HIP);
     if (hipHostMalloc(reinterpret_cast<void**>(&c->s2_stats_host), 64, hipHostMallocDefault) != hipSuccess) return fail(GSX_E_NOMEM);
     std::memset(c->s2_stats_host, 0, 64);
     for (int b = 0; b < GSX_PERM_RING; ++b)
-        if (hipEventCreateWithFlags(&c->ev_frame_done[b], hipEventDisableTiming) != hipSuccess) return fail(GSX_E_HIP);
+        if (hipEventCreateWithFlags(&c->ev_frame_done[b], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&c->ev_perm[b], hipEventDisableTiming) != hipSuccess)
+            return fail(GSX_E_HIP);
     c->sel_stream = c->stream;
     if (gsx_scratch_init(c, device) != GSX_OK) return fail(GSX_E_HIP);
     {
@@ -190,8 +194,12 @@ int gsx_destroy(gsx_ctx* c) {
     if (c->flags_host) (void)hipHostFree(c->flags_host);
     for (int i = 0; i < EV_COUNT; ++i)
         if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
-    for (hipEvent_t e : {c->ev_sorted, c->ev_pre, c->ev_frame_done[0], c->ev_frame_done[1], c->ev_frame_done[2]})
+    for (hipEvent_t e : {c->ev_sorted, c->ev_pre, c->ev_sample_done})
         if (e) (void)hipEventDestroy(e);
+    for (int b = 0; b < GSX_PERM_RING; ++b) {
+        if (c->ev_frame_done[b]) (void)hipEventDestroy(c->ev_frame_done[b]);
+        if (c->ev_perm[b]) (void)hipEventDestroy(c->ev_perm[b]);
+    }
     for (auto& g : c->gathers)
         if (g.ev) (void)hipEventDestroy(g.ev);
     if (c->ev_comm_pre) (void)hipEventDestroy(c->ev_comm_pre);
@@ -247,6 +255,11 @@ int gsx_set_option(gsx_ctx* c, const char* name, uint64_t value) {
         c->s2_backoff = c->s2_backoff_len = 0;
     } else if (!std::strcmp(name, "async_sort")) {
         c->opt_async_sort = value ? 1 : 0;
+    } else if (!std::strcmp(name, "sort_ahead")) {
+        // 1: gsx_render draws the oldest permutation not drawn yet, so the caller may queue the next frame's sort before this
+        // frame (sort k+1, render k, sort k+2, render k+1 ...); setting the option forgets permutations that wait to be drawn
+        c->opt_sort_ahead = value ? 1 : 0;
+        c->undrawn = 0;
     } else if (!std::strcmp(name, "frames_in_flight")) {
         if (value < 1 || value > 2) { c->err = "frames_in_flight must be 1 or 2"; return GSX_E_INVALID; }
         int rc = set_device(c);
@@ -362,6 +375,8 @@ static int upload_common(gsx_ctx* c, const void* aos_dev, uint64_t n) {
     c->hist_valid = false;
     c->parked.hist_valid = false;
     c->sorted_rec = false;
+    c->undrawn = 0;
+    for (bool& r : c->perm_rec) r = false;
     if ((rc = alloc_scene(c, n))) return rc;
     c->n = n;
     GSX_HIP(c, hipMemsetAsync(c->flags, 0, sizeof(GsxDevFlags), c->stream));
@@ -636,8 +651,12 @@ int gsx_get_selection(gsx_ctx* c, uint32_t* idx_out, uint32_t capacity, uint32_t
     return GSX_OK;
 }
 
+// GSX_TRACE_HOST=1: when the host enters and leaves gsx_sort / gsx_render (CLOCK_MONOTONIC, us - the clock of rocprofv3's
+// kernel timestamps; tools/host_vs_gpu.py merges the two)
+static const bool g_dbg_host = getenv("GSX_TRACE_HOST") != nullptr;
 int gsx_sort(gsx_ctx* c, const float cam_pos[3], uint32_t* idx_out_host) {
     if (!c || !cam_pos) return GSX_E_INVALID;
+    struct DbgExit { double t0; ~DbgExit() { if (g_dbg_host) fprintf(stderr, "[host] sort %.1f .. %.1f\n", t0, gsx_dbg_now()); } } dbg_exit{g_dbg_host ? gsx_dbg_now() : 0.0};
     int rc = set_device(c);
     if (rc) return rc;
     // A frame in flight reads perm[perm_cur]; this sort writes the other buffer, so it is queued behind that frame without
@@ -713,6 +732,8 @@ int gsx_render(gsx_ctx* c, const gsx_uniforms* u, uint32_t width, uint32_t heigh
     if (!c->sorted_valid) { c->err = "gsx_render before gsx_sort"; return GSX_E_STATE; }
     int rc = set_device(c);
     if (rc) return rc;
+    double dbg_t1 = 0.0;
+    struct DbgExit { double t0; double* t1; ~DbgExit() { if (g_dbg_host) fprintf(stderr, "[host] render %.1f wait-done %.1f .. %.1f\n", t0, *t1, gsx_dbg_now()); } } dbg_exit{g_dbg_host ? gsx_dbg_now() : 0.0, &dbg_t1};
     if (c->opt_frames_in_flight >= 2 && !c->profiling && c->parked.fstream) {
         // two frames in flight: this frame takes the slot of the frame before the last one (long finished, as a rule) and is
         // queued beside the last one, which the host does not wait for
@@ -721,8 +742,19 @@ int gsx_render(gsx_ctx* c, const gsx_uniforms* u, uint32_t width, uint32_t heigh
     } else if ((rc = gsx_frame_finish(c))) {
         return rc;
     }
-    if (c->sorted_rec) GSX_HIP(c, hipStreamWaitEvent(c->fstream, c->ev_sorted, 0));   // the permutation (sorted on another stream, maybe)
-    if (c->fstream == c->stream) c->sort_join_pending = false;
+    if (g_dbg_host) dbg_t1 = gsx_dbg_now();
+    // the permutation this frame draws: the latest one, or - option sort_ahead, two sorts since the last frame - the one before it
+    c->perm_draw = (c->opt_sort_ahead && c->undrawn >= 2u) ? (c->perm_cur + GSX_PERM_RING - 1u) % GSX_PERM_RING : c->perm_cur;
+    if (c->undrawn) --c->undrawn;
+    bool behind_latest = false;          // this frame's stream is behind the LATEST sort (the main stream's pending join is then done)
+    if (c->perm_draw != c->perm_cur && c->perm_rec[c->perm_draw]) {
+        GSX_HIP(c, hipStreamWaitEvent(c->fstream, c->ev_perm[c->perm_draw], 0));
+    } else {
+        if (c->sorted_rec) GSX_HIP(c, hipStreamWaitEvent(c->fstream, c->ev_sorted, 0));   // (sorted on another stream, maybe)
+        behind_latest = true;
+    }
+    if ((rc = gsx_behind_sample(c, c->fstream))) return rc;
+    if (c->fstream == c->stream && behind_latest) c->sort_join_pending = false;
     if ((rc = gsx_launch_render(c, u, width, height, y0, y1))) return rc;
     c->ev_recorded[EV_RAST1] = c->profiling;
     if (rgba8_out_host) {

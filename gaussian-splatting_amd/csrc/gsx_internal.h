@@ -10,7 +10,7 @@
 
 #define GSX_WAVE 64
 #define GSX_SAMPLE_RING 32
-#define GSX_PERM_RING 3           // permutation buffers: two frames in flight read two of them while the next sort fills the third
+#define GSX_PERM_RING 4           // permutation buffers: two frames in flight read two of them, a third may wait to be drawn (option sort_ahead) while the next sort fills the fourth
 #define GSX_SAMPLE_WHOLE 4
 #define GSX_SAMPLE_EVERY 8u       // profiling level 2 samples every 8th sort by default (gsx_set_option "sample_every")
 #define GSX_GATHER_RING 4          // exchanges whose memory ranges are remembered (an older one still running is waited for on the host)
@@ -123,6 +123,8 @@ struct GsxGeo {
 // while frame k is still running (the kernels of one frame leave much of the GPU idle: single-workgroup scans, dependent
 // launches, the rasterizer's tail), and the host never waits for frame k before it queues frame k+1.  gsx_ctx derives from
 // the ACTIVE slot, so the frame loop's code reads c->ctl, c->pair_key ... as before; gsx_slot_switch swaps the two.
+#include <ctime>
+static inline double gsx_dbg_now() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3; }
 struct GsxFrameSlot {
     hipStream_t fstream = nullptr;     // the stream this slot's frames are queued on (slot 0: the context's main stream)
     uint64_t frame_seq = 0;            // launch order of the frame in this slot (older frames are finished first)
@@ -292,6 +294,17 @@ struct gsx_ctx : GsxFrameSlot {
     hipEvent_t ev_sorted = nullptr, ev_pre = nullptr, ev_frame_done[GSX_PERM_RING] = {};
     bool frame_done_rec[GSX_PERM_RING] = {};
     bool sorted_rec = false;              // ev_sorted has been recorded (behind the latest sort, on whichever stream it ran)
+    // Option sort_ahead: the caller queues the sort of frame k+1 BEFORE it queues frame k, so that the sort is on the device while
+    // the host is still launching frame k's kernels (in call order sort k, render k, sort k+1 the launches of render k - some
+    // thirty of them - stand between the two sorts, and the device waits for the host).  gsx_render then draws the OLDEST
+    // permutation not drawn yet (at most two wait), each behind the event of its own sort.
+    uint64_t opt_sort_ahead = 0;
+    hipEvent_t ev_sample_done = nullptr;  // end of the latest sampled sort (profiling level 2): it is timed alone on the device
+    bool sample_pending = false;
+    uint32_t undrawn = 0;                 // permutations sorted since the last gsx_render (<= 1 without sort_ahead, <= 2 with it)
+    uint32_t perm_draw = 0;               // ring slot the frame being queued draws from
+    hipEvent_t ev_perm[GSX_PERM_RING] = {};   // end of the sort that filled ring slot b (recorded with sort_ahead)
+    bool perm_rec[GSX_PERM_RING] = {};
     uint64_t opt_frames_in_flight = 2;
     uint32_t opt_sample_every = GSX_SAMPLE_EVERY;   // profiling level 2: every how many sorts one is a sampled (synchronous) one
     bool sort_join_pending = false;      // a sort was queued on sort_stream and the main stream has not waited for it yet
@@ -377,6 +390,7 @@ int gsx_launch_select_band(gsx_ctx* c, const float wt[16], const float proj[16],
 int gsx_launch_sort_list(gsx_ctx* c, uint32_t m); // ascending re-order of an explicit index list
 int gsx_launch_render(gsx_ctx* c, const gsx_uniforms* u, uint32_t w, uint32_t h, uint32_t y0, uint32_t y1);
 void gsx_sample_drain(gsx_ctx* c, uint32_t slot);   // folds a finished level-2 sample into samp_sum_ms / samp_n
+int gsx_behind_sample(gsx_ctx* c, hipStream_t st);                 // work queued on st next starts behind a sampled sort that is still running
 void gsx_join_sort(gsx_ctx* c);                  // main stream waits for the sort stream's latest sort (no host wait)
 int gsx_frame_finish(gsx_ctx* c);                // waits for every queued frame (oldest first); runs extra iterations if ranks are left
 int gsx_frame_finish_active(gsx_ctx* c);         // the same for the active slot's frame only

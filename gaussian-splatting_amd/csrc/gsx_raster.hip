@@ -922,6 +922,7 @@ static void mul44_glm(const float* a, const float* b, float* out) {
 template <typename T>
 static int ensure(gsx_ctx* c, T** p, uint64_t* cap, uint64_t need, bool exact = false) {
     if (need <= *cap && *p) return GSX_OK;
+    if (std::getenv("GSX_TRACE")) std::fprintf(stderr, "[gsx] %.1f ensure: %llu -> %llu elements of %zu bytes\n", gsx_dbg_now(), (unsigned long long)*cap, (unsigned long long)need, sizeof(T));
     if (*p) GSX_HIP(c, hipFree(*p));
     *p = nullptr; *cap = 0;
     const uint64_t want = exact ? need : need + need / 4 + 1024;
@@ -1153,7 +1154,7 @@ int gsx_launch_render(gsx_ctx* c, const gsx_uniforms* u, uint32_t w, uint32_t h,
     GsxFrameState& f = c->frame;
     std::memcpy(f.vp_blob, &vp, sizeof(vp));
     f.mode = mode;
-    f.sorted = c->perm[c->perm_cur];
+    f.sorted = c->perm[c->perm_draw];
     f.n_tiles = n_tiles;
     f.continuing = false;
     f.caps_on = cap_radius >= 0;
@@ -1163,7 +1164,7 @@ int gsx_launch_render(gsx_ctx* c, const gsx_uniforms* u, uint32_t w, uint32_t h,
     // (K3, the projection, runs inside k_chunk_count on the ranks each iteration reaches)
     if (c->profiling && c->stat) GSX_HIP(c, hipMemsetAsync(c->stat, 0, GSX_STAT_BYTES, c->fstream));
     if (c->profiling) GSX_HIP(c, hipEventRecord(c->ev[EV_PROJ0], c->fstream));
-    hipLaunchKernelGGL(k_frame_init, dim3(vp.tiles_y), dim3(256), 0, c->fstream, c->ctl, c->m_perm + c->perm_cur, c->live_bits,
+    hipLaunchKernelGGL(k_frame_init, dim3(vp.tiles_y), dim3(256), 0, c->fstream, c->ctl, c->m_perm + c->perm_draw, c->live_bits,
                        c->tile_state, vp.tiles_x, vp.tiles_y, c->aux, c->tile_depth[depth_prev], c->tile_depth[c->depth_cur], c->tile_band,
                        c->band_masks, cap_exact ? 0 : cap_radius, cap_exact ? 256u : (c->opt_tile_caps == 2 ? 32u : 384u),
                        (cap_exact || c->opt_tile_caps == 2) ? 0u : 2048u);
@@ -1308,8 +1309,8 @@ int gsx_frame_finish_active(gsx_ctx* c) {
         const GsxFrameCtl& h = *c->ctl_host;
         const uint32_t cur = h.cursor[last];
         if (trace)
-            std::fprintf(stderr, "[gsx] frame: iters=%u last=%u cursor=%u m=%u live=%u pairs=%u total=%u max=%u used=%u stall=%u budget=%llu opt=%llu grown=%llu alloc=%llu ctx=%p\n",
-                         f.n_iters, last, cur, h.m, h.live_tiles, h.pairs, h.total_pairs, h.max_pairs, h.iters_used, h.stall,
+            std::fprintf(stderr, "[gsx] %.1f slot-stream %p main %d frame: iters=%u last=%u cursor=%u m=%u live=%u pairs=%u total=%u max=%u used=%u stall=%u budget=%llu opt=%llu grown=%llu alloc=%llu ctx=%p\n",
+                         gsx_dbg_now(), (void*)c->fstream, (int)(c->fstream == c->stream), f.n_iters, last, cur, h.m, h.live_tiles, h.pairs, h.total_pairs, h.max_pairs, h.iters_used, h.stall,
                          static_cast<unsigned long long>(c->pair_cap), static_cast<unsigned long long>(c->opt_pair_budget),
                          static_cast<unsigned long long>(c->pair_grown), static_cast<unsigned long long>(c->pair_alloc), static_cast<void*>(c));
         if (cur >= h.m || h.live_tiles == 0u) {
@@ -1325,6 +1326,7 @@ int gsx_frame_finish_active(gsx_ctx* c) {
                     c->caps_backoff = c->caps_backoff ? (c->caps_backoff < 64u ? c->caps_backoff * 2u : 64u) : 4u;
                     c->caps_off_frames = c->caps_backoff;
                     int rc;
+                    if ((rc = gsx_behind_sample(c, c->fstream)) != GSX_OK) { c->frame_pending = false; return rc; }   // (a sampled sort is timed alone)
                     GSX_HIP(c, hipMemcpyAsync(&c->ctl->cursor[0], &start, 4, hipMemcpyHostToDevice, c->fstream));
                     GSX_HIP(c, hipMemcpyAsync(&c->ctl->stall, &zero, 4, hipMemcpyHostToDevice, c->fstream));
                     if ((rc = launch_iteration(c, 0, h.m - start, false)) != GSX_OK) { c->frame_pending = false; return rc; }
@@ -1349,6 +1351,7 @@ int gsx_frame_finish_active(gsx_ctx* c) {
         }
         // restart the cursor ring at slot 0 and run one more iteration over everything that is left
         const uint32_t zero = 0;
+        if ((rc = gsx_behind_sample(c, c->fstream)) != GSX_OK) { c->frame_pending = false; return rc; }   // (a sampled sort is timed alone)
         GSX_HIP(c, hipMemcpyAsync(&c->ctl->cursor[0], &c->ctl->cursor[last], 4, hipMemcpyDeviceToDevice, c->fstream));
         GSX_HIP(c, hipMemcpyAsync(&c->ctl->stall, &zero, 4, hipMemcpyHostToDevice, c->fstream));
         if ((rc = launch_iteration(c, 0, h.m - cur, false)) != GSX_OK) { c->frame_pending = false; return rc; }

@@ -254,6 +254,9 @@ struct GsxSortBuffers {
     uint32_t* m_copy = nullptr;   // device word that receives the selection's size (the context's own sort only)
 };
 
+// GSX_DEBUG_SORT2=1: the bucket statistics of every two-pass sort, the plan of every sampled sort and every sample, on stderr
+static const bool g_dbg_sort2 = getenv("GSX_DEBUG_SORT2") != nullptr;
+
 static int launch_sort_in(gsx_ctx* c, const GsxSortBuffers& sb, hipStream_t st) {
     const uint32_t cap = c->m_cap;
     const uint32_t g = gsx_radix_blocks(cap, GSX_SORT_TILE, c->sort_slots);
@@ -279,7 +282,7 @@ static int launch_sort_in(gsx_ctx* c, const GsxSortBuffers& sb, hipStream_t st) 
     if (sb.two_pass_ok && c->s2_pairs && c->opt_sort_algo != 1) {
         if (c->s2_stats_rec && hipEventQuery(c->ev_s2_stats) == hipSuccess) {
             c->s2_stats_rec = false;
-            if (getenv("GSX_DEBUG_SORT2")) fprintf(stderr, "[gsx] two-pass stats: big_buckets %u big_keys %u max_bucket %u (cap %u)\n", c->s2_stats_host->big_buckets, c->s2_stats_host->big_keys, c->s2_stats_host->max_bucket, cap);
+            if (g_dbg_sort2) fprintf(stderr, "[gsx] two-pass stats: big_buckets %u big_keys %u max_bucket %u (cap %u)\n", c->s2_stats_host->big_buckets, c->s2_stats_host->big_keys, c->s2_stats_host->max_bucket, cap);
             if (static_cast<uint64_t>(c->s2_stats_host->big_keys) * 64ull > cap) {
                 c->s2_backoff_len = c->s2_backoff_len ? (c->s2_backoff_len < 512u ? c->s2_backoff_len * 2u : 1024u) : 16u;
                 c->s2_backoff = c->s2_backoff_len;
@@ -307,6 +310,8 @@ static int launch_sort_in(gsx_ctx* c, const GsxSortBuffers& sb, hipStream_t st) 
         samp_b[what] = c->samp_ev[slot][1];
     };
     int sampled_pass = -1;
+    if (g_dbg_sort2 && c->prof_level == 2 && c->prof_frame % c->opt_sample_every == 0u)
+        fprintf(stderr, "[gsx] %.1f sampled sort %llu: two-pass %d nd %u ncols %u key_lo %#x key_span %#x\n", gsx_dbg_now(), (unsigned long long)c->prof_frame, (int)p2.ok, p2.nd, p2.ncols, key_lo, key_span);
     if (sb.with_events) {
         if (c->prof_level == 2 && n_stage > 0 && c->prof_frame % c->opt_sample_every == 0u) {
             if ((c->prof_frame / c->opt_sample_every) % 2u == 1u) {
@@ -384,7 +389,8 @@ static int launch_sort_in(gsx_ctx* c, const GsxSortBuffers& sb, hipStream_t st) 
     if (sampled_pass == GSX_SAMPLE_WHOLE) GSX_HIP(c, hipEventRecord(samp_b[GSX_SAMPLE_WHOLE], st));
     // bucket statistics of a two-pass sort for the next sorts' choice of form: every 4th sort, read when the copy has landed,
     // never waited for (a 16-byte copy is a 4 us blit on the stream)
-    if (want_stats && !c->s2_stats_rec && (c->s2_stats_tick++ & 3u) == 0u) {
+    const bool stats_always = g_dbg_sort2;     // (debug: the statistics of every sort)
+    if (want_stats && !c->s2_stats_rec && ((c->s2_stats_tick++ & 3u) == 0u || stats_always)) {
         const Gsx2Workspace w = gsx2_ws_carve(c->s2_ws, c->sort_cap);
         GSX_HIP(c, hipMemcpyAsync(c->s2_stats_host, w.stats, sizeof(Gsx2Stats), hipMemcpyDeviceToHost, st));
         GSX_HIP(c, hipEventRecord(c->ev_s2_stats, st));
@@ -398,6 +404,15 @@ static int launch_sort_in(gsx_ctx* c, const GsxSortBuffers& sb, hipStream_t st) 
         c->sort_two_pass = p2.ok;
         c->sort_launches = p2.ok ? 5u : 3u * static_cast<uint32_t>(plan.n_passes) - 1u;   // (pass 0's count is fused into the key kernel)
     }
+    return GSX_OK;
+}
+
+// Work about to be queued on `st` starts behind the latest sampled sort, if that one has not ended yet (the device runs far
+// behind the host: a continuation the host launches two frames later can still meet it).
+int gsx_behind_sample(gsx_ctx* c, hipStream_t st) {
+    if (!c->sample_pending) return GSX_OK;
+    if (hipEventQuery(c->ev_sample_done) == hipSuccess) { c->sample_pending = false; return GSX_OK; }
+    if (st != c->stream) GSX_HIP(c, hipStreamWaitEvent(st, c->ev_sample_done, 0));
     return GSX_OK;
 }
 
@@ -435,6 +450,13 @@ int gsx_launch_sort(gsx_ctx* c) {
         if (c->pre_wait) { GSX_HIP(c, hipStreamWaitEvent(st, c->ev_pre, 0)); c->pre_wait = false; }
     } else {
         gsx_join_sort(c);                // behind the sort stream's latest sort: same arrays
+        if (sampled) {
+            // a sampled sort is timed as the kernels' own: it starts behind every frame that is queued (the other slot's frame
+            // runs on a stream of its own), and whatever is queued on another stream before it has ended starts behind it
+            // (gsx_behind_sample) - one bubble per sample
+            for (GsxFrameSlot* sl : {static_cast<GsxFrameSlot*>(c), &c->parked})
+                if (sl->frame_pending && sl->fstream != c->stream) GSX_HIP(c, hipStreamWaitEvent(c->stream, sl->frame_ev, 0));
+        }
     }
     // the last frame that drew from the buffer this sort overwrites (three buffers: the frame before the two that may be in flight)
     if (c->frame_done_rec[target]) GSX_HIP(c, hipStreamWaitEvent(st, c->ev_frame_done[target], 0));
@@ -442,6 +464,16 @@ int gsx_launch_sort(gsx_ctx* c) {
     if (rc != GSX_OK) return rc;
     GSX_HIP(c, hipEventRecord(c->ev_sorted, st));   // what a frame's stream waits for before it draws this permutation
     c->sorted_rec = true;
+    if (sampled && c->ev_sample_done) {
+        GSX_HIP(c, hipEventRecord(c->ev_sample_done, st));
+        c->sample_pending = true;
+    }
+    c->perm_rec[target] = false;
+    if (c->opt_sort_ahead && c->ev_perm[target]) {  // (a frame may draw this permutation after the NEXT sort has re-recorded ev_sorted)
+        GSX_HIP(c, hipEventRecord(c->ev_perm[target], st));
+        c->perm_rec[target] = true;
+    }
+    c->undrawn = c->undrawn + 1u > (c->opt_sort_ahead ? 2u : 1u) ? (c->opt_sort_ahead ? 2u : 1u) : c->undrawn + 1u;
     if (async) {
         c->sort_join_pending = true;
     } else if (c->sort_stream) {
@@ -538,6 +570,7 @@ void gsx_sample_drain(gsx_ctx* c, uint32_t slot) {
     float ms = 0.0f;
     if (hipEventSynchronize(c->samp_ev[slot][1]) != hipSuccess) return;
     if (hipEventElapsedTime(&ms, c->samp_ev[slot][0], c->samp_ev[slot][1]) != hipSuccess) return;
+    if (g_dbg_sort2) fprintf(stderr, "[gsx] sample: what %d  %.4f ms\n", p, ms);
     if (p <= GSX_SAMPLE_WHOLE) { c->samp_sum_ms[p] += ms; ++c->samp_n[p]; }
     if (p < GSX_SAMPLE_WHOLE) { c->samp_last_ms = ms; c->samp_last_pass = p; }
 }

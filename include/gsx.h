@@ -140,6 +140,12 @@ int gsx_get_sort_samples(gsx_ctx* ctx, double* sum_ms, uint32_t* sorts, int rese
  *                   Same permutation either way (distance descending, index ascending).
  *   "async_sort"    0 = queue LOD cuts and depth sorts on the main stream, behind the frame in flight (default 1: on a
  *                   stream of their own, beside it; same results)
+ *   "sort_ahead"    1 = gsx_render draws the OLDEST permutation that has not been drawn yet (at most two wait; a third sort
+ *                   before any frame drops the oldest), so a viewer can call sort(k+1), render(k), sort(k+2), render(k+1) ...:
+ *                   the next frame's sort reaches the device before the host has worked through this frame's ~30 launches, and
+ *                   every frame still draws the permutation sorted for its own camera.  Default 0: gsx_render draws the latest
+ *                   permutation (the reference's sortSplats-then-draw order, SplatMesh.h:84-114 + main.cpp:359-368).  Setting
+ *                   the option, to either value, forgets permutations that wait to be drawn (the latest one stays current).
  *   "frames_in_flight"  1 = wait for frame k before queuing frame k + 1 (default 2: frame k + 1 is binned and rasterized on a
  *                   second frame slot while frame k is still running; same pixels)
  *   "tile_caps"     0 = bin every live tile through the whole window (default 1: a tile is binned only up to 1.5 x the depth
@@ -149,7 +155,8 @@ int gsx_get_sort_samples(gsx_ctx* ctx, double* sum_ms, uint32_t* sorts, int rese
  *   "tile_caps_radius"  largest neighbourhood radius (in tiles, default 4, at most 32) up to which a moving view still uses the
  *                   rank caps; the radius needed follows from how far the scene moved on screen since the slot's last frame
  *   "sample_every"  profiling level 2: every how many sorts one is a sampled one (default 8; a sampled sort runs on the main
- *                   stream, beside nothing, so that its events time the kernel itself - which costs that frame the overlap)
+ *                   stream behind every queued frame, and what is queued on the other streams while it runs starts behind it,
+ *                   so that its events time the kernels themselves - which costs the pipeline one bubble per sample)
  *   "sort_slots", "pair_slots"  workgroups the scatter kernels of the depth sort / of the binner's pair sort keep resident
  *                   (8 .. 2048; default: as many as the GPU holds, 512 on MI355X); fewer leave registers and LDS to the
  *                   kernels of the context's other streams (measured: no gain)

@@ -577,6 +577,48 @@ def test_frames_queued_back_to_back(gsx_fresh, pkg, oracle, synth):
     assert whole_ms > max(m2.values())
 
 
+def test_sort_ahead_draws_each_pose_from_its_own_permutation(gsx_fresh, pkg, oracle, synth):
+    # option sort_ahead: the caller queues frame k+1's sort BEFORE frame k; gsx_render draws the oldest permutation not drawn
+    # yet, so every frame is byte-identical to the in-order call sequence (sort k, render k)
+    gsx = gsx_fresh
+    w, h = 240, 176
+    splats = dense_scene(oracle, synth, 20000, seed=7)
+    gsx.upload(splats)
+    cams = [camera(oracle, w, h, steps=s) for s in (0, 3, 6, 9, 12)]
+    unis = [pkg.make_uniforms(proj, view) for view, proj, _ in cams]
+    ref = []
+    for (view, proj, cam), u in zip(cams, unis):
+        gsx.sort(cam, download=False)
+        ref.append(gsx.render(u, w, h).copy())
+    assert not np.array_equal(ref[0], ref[1]) and not np.array_equal(ref[1], ref[2])
+    gsx.set_option("sort_ahead", 1)
+    gsx.sort(cams[0][2], download=False)
+    for k in range(len(cams)):
+        if k + 1 < len(cams):
+            gsx.sort(cams[k + 1][2], download=False)       # the NEXT pose's sort first ...
+        gsx.render(unis[k], w, h, download=False)          # ... then this pose's frame, from the permutation sorted one step ago
+        if k % 2:                                          # (every other frame is left in flight while the next two calls are queued)
+            gsx.sync()
+        ptr, fw, fh = gsx.framebuffer_dev()
+        if k % 2:
+            assert np.array_equal(_read_device(ptr, w * h * 4).reshape(h, w, 4), ref[k]), f"sort_ahead: frame {k} differs"
+    gsx.sync()
+    ptr, _, _ = gsx.framebuffer_dev()
+    assert np.array_equal(_read_device(ptr, w * h * 4).reshape(h, w, 4), ref[-1])
+    # a third sort before any frame: only two permutations wait, the oldest of the three is dropped
+    for k in (0, 1, 2):
+        gsx.sort(cams[k][2], download=False)
+    assert np.array_equal(gsx.render(unis[1], w, h), ref[1])
+    assert np.array_equal(gsx.render(unis[2], w, h), ref[2])
+    assert np.array_equal(gsx.render(unis[2], w, h), ref[2])      # nothing waits any more: the latest one again
+    # setting the option forgets what waits; without it the latest sort wins as before
+    gsx.sort(cams[3][2], download=False)
+    gsx.set_option("sort_ahead", 0)
+    gsx.sort(cams[4][2], download=False)
+    gsx.sort(cams[0][2], download=False)
+    assert np.array_equal(gsx.render(unis[0], w, h), ref[0])
+
+
 def test_render_into_caller_owned_target(gsx_fresh, pkg, oracle, synth):
     # gsx_set_framebuffer_dev: frames go straight into caller-owned device memory (the slots of the multi-GPU view
     # batches); byte-identical to the library's own framebuffer, nothing written past width*height*4

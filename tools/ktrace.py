@@ -15,5 +15,5 @@ t0 = int(rows[0]["Start_Timestamp"])
 for r in rows:
     s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
     gap = (s - prev) / 1e3 if prev else 0.0
-    print(f"{(s - t0) / 1e3:9.1f} us  dur {(e - s) / 1e3:8.1f}  gap {gap:6.1f}  grid {r.get('Grid_Size_X', r.get('Grid_Size', '?')):>9s}  {r['Kernel_Name'][:70]}")
+    print(f"{(s - t0) / 1e3:9.1f} us  end {(e - t0) / 1e3:9.1f}  q{r.get('Queue_Id', '?'):>2s}  dur {(e - s) / 1e3:8.1f}  gap {gap:6.1f}  grid {r.get('Grid_Size_X', r.get('Grid_Size', '?')):>9s}  {r['Kernel_Name'][:70]}")
     prev = e
