@@ -1175,6 +1175,16 @@ int gsx_launch_render(gsx_ctx* c, const gsx_uniforms* u, uint32_t w, uint32_t h,
     // frame does need more, gsx_frame_finish runs the rest (correct, just not pre-queued).
     uint64_t need = c->need_pos ? 0 : ~0u;
     for (uint32_t k = 0; k < 8 && k < c->need_pos; ++k) need = c->need_hist[k] > need ? c->need_hist[k] : need;
+    if (c->need_pos >= 2) {
+        // a camera moving into the scene needs 20-30 % more ranks from one frame to the next, and the latest depth known here is
+        // two frames old (two frames in flight): continue the trend of the last two, or the frame ends with live tiles and the
+        // host has to run a continuation over everything that is left (5 of the 120 orbit frames of cfg 2 did)
+        const uint64_t last = c->need_hist[(c->need_pos - 1u) % 8u], prev = c->need_hist[(c->need_pos - 2u) % 8u];
+        if (last != ~0u && prev != ~0u && last > prev) {
+            const uint64_t ahead = last + 2u * (last - prev);
+            need = ahead > need ? ahead : need;
+        }
+    }
     if (need > m_cap) need = m_cap;
     c->frame.need_base = static_cast<uint32_t>(need);
     {   // margin: 12 % plus a quarter of the depth again (at least 2 K, at most 32 K ranks) — a fixed 32 K margin
@@ -1354,7 +1364,14 @@ int gsx_frame_finish_active(gsx_ctx* c) {
         if ((rc = gsx_behind_sample(c, c->fstream)) != GSX_OK) { c->frame_pending = false; return rc; }   // (a sampled sort is timed alone)
         GSX_HIP(c, hipMemcpyAsync(&c->ctl->cursor[0], &c->ctl->cursor[last], 4, hipMemcpyDeviceToDevice, c->fstream));
         GSX_HIP(c, hipMemcpyAsync(&c->ctl->stall, &zero, 4, hipMemcpyHostToDevice, c->fstream));
-        if ((rc = launch_iteration(c, 0, h.m - cur, false)) != GSX_OK) { c->frame_pending = false; return rc; }
+        // (half as many ranks again as the frame has consumed, at least 256 K: the few tiles that are still live rarely need
+        //  more, and a window over everything that is left projects millions of hidden ranks; the loop comes round if they do)
+        uint32_t cont = h.m - cur;
+        {
+            const uint32_t want = cur / 2u > (256u << 10) ? cur / 2u : (256u << 10);
+            if (cont > want + want / 2u) cont = (want + 1023u) / 1024u * 1024u;
+        }
+        if ((rc = launch_iteration(c, 0, cont, false)) != GSX_OK) { c->frame_pending = false; return rc; }
         GSX_HIP(c, hipMemcpyAsync(c->ctl_host, c->ctl, GSX_AUX_OFFSET + 128, hipMemcpyDeviceToHost, c->fstream));
         gsx_mark_frame_done(c);
         GSX_HIP(c, hipStreamSynchronize(c->fstream));
