@@ -68,7 +68,8 @@ def sort_bytes_per_splat(passes, iota=True, form=1):
     if passes <= 0:
         return KEYGEN_BYTES_PER_SPLAT
     first = SCATTER_BYTES_PASS0 if iota else SCATTER_BYTES_PASSN
-    return KEYGEN_BYTES_PER_SPLAT + first + (passes - 1) * (SCATTER_BYTES_PASSN + COUNT_BYTES_PER_SPLAT)
+    dead = 4 if passes < 4 else 0      # the last pass does not store its keys (unless a gated fourth pass sorts on them)
+    return KEYGEN_BYTES_PER_SPLAT + first + (passes - 1) * (SCATTER_BYTES_PASSN + COUNT_BYTES_PER_SPLAT) - dead
 
 
 def load_pkg():
@@ -137,22 +138,35 @@ def kernel_rooflines_from_profile(n_splats):
     """HBM rates of the key / count / cull+projection / LOD kernels from the committed rocprofv3 --kernel-trace --stats summaries
     (tools/final_profile.sh runs this command once more with everything on ONE stream, so that the durations are the kernels'
     own; tools/lod_profile.sh profiles cfg 3).  Not measured in this run: every figure cites its file."""
-    path = os.path.join(ROOT, "profiles", "r2_bench_serialized_kernel_stats.csv")
+    path = os.path.join(ROOT, "profiles", "r3_bench_serialized_kernel_stats.csv")
     if not os.path.exists(path):
         return None
     bytes_per_call = {   # algorithmic bytes per launch at n_splats splats (DESIGN.md section 4)
-        "k_keygen_hist0": KEYGEN_BYTES_PER_SPLAT * n_splats,
-        "k_radix_hist<unsigned int": COUNT_BYTES_PER_SPLAT * n_splats,
+        "k2_keygen_hist": KEYGEN_BYTES_PER_SPLAT * n_splats,      # 16 B position in, 4 B key out (the 2-byte bucket counts ride along)
+        "k2_partition": PARTITION_BYTES * n_splats,
+        "k2_local<18>": None,                                       # (the two bucket-sort instances share the pairs: priced together below)
+        "k2_local<8>": None,
+        "k2_scan": None,
     }
-    out = {"source": "profiles/r2_bench_serialized_kernel_stats.csv (rocprofv3 --kernel-trace --stats of `python bench.py --cpu-frames 0 "
-                     "--opt async_sort=0 --opt frames_in_flight=1`; not measured in this run)"}
+    out = {"source": "profiles/r3_bench_serialized_kernel_stats.csv (rocprofv3 --kernel-trace --stats of `python bench.py --cpu-frames 0 "
+                     "--in-order --opt async_sort=0 --opt frames_in_flight=1`: one stream, one frame at a time; not measured in this run)"}
+    local_us = 0.0
     for r in csv.DictReader(open(path)):
         for key, b in bytes_per_call.items():
             if key in r["Name"]:
                 avg_us = float(r["AverageNs"]) / 1e3
-                out[key.split("<")[0]] = {"avg_us": avg_us, "calls": int(r["Calls"]), "algorithmic_bytes": b,
-                                          "hbm_gbs": b / (avg_us * 1e-6) / 1e9, "hbm_frac": b / (avg_us * 1e-6) / 1e9 / HBM_PEAK_GBS}
-    for name, fn in (("k_chunk_count", "r2_chunk_count_roofline.json"), ("lod_cut_cfg3", "r2_cfg3_lod_roofline.json")):
+                rec = {"avg_us": avg_us, "calls": int(r["Calls"])}
+                if b:
+                    rec.update(algorithmic_bytes=b, hbm_gbs=b / (avg_us * 1e-6) / 1e9, hbm_frac=b / (avg_us * 1e-6) / 1e9 / HBM_PEAK_GBS)
+                if key.startswith("k2_local"):
+                    local_us += avg_us
+                out[key] = rec
+    if local_us > 0.0:
+        b = LOCAL_BYTES * n_splats
+        out["k2_local (both instances)"] = {"avg_us": local_us, "algorithmic_bytes": b, "hbm_gbs": b / (local_us * 1e-6) / 1e9,
+                                            "hbm_frac": b / (local_us * 1e-6) / 1e9 / HBM_PEAK_GBS}
+    for name, fn in (("k_chunk_count", "r3_chunk_count_roofline.json"), ("lod_cut_cfg3", "r2_cfg3_lod_roofline.json"),
+                     ("sort_pmc_traffic", "r3_sort_traffic.json")):
         p = os.path.join(ROOT, "profiles", fn)
         if os.path.exists(p):
             out[name] = dict(json.load(open(p)), source="profiles/" + fn)
@@ -546,7 +560,8 @@ def main():
             stage_bytes = {0: PARTITION_BYTES, 1: LOCAL_BYTES}
             launch_bytes = {p: stage_bytes.get(p, LOCAL_BYTES) * n for p in per_pass}
         else:   # (pass 0 of the radix form generates the index: 12 B per key)
-            launch_bytes = {p: (SCATTER_BYTES_PASS0 if p == 0 else SCATTER_BYTES_PASSN) * n for p in per_pass}
+            launch_bytes = {p: ((SCATTER_BYTES_PASS0 if p == 0 else SCATTER_BYTES_PASSN) - (4 if (n_pass < 4 and p == n_pass - 1) else 0)) * n
+                            for p in per_pass}      # (the last ungated pass stores no keys)
         sum_ms = sum(per_pass[p] * pass_n[p] for p in per_pass)
         sum_bytes = sum(launch_bytes[p] * pass_n[p] for p in per_pass)
         launches = sum(pass_n.values())

@@ -372,7 +372,9 @@ static int launch_sort_in(gsx_ctx* c, const GsxSortBuffers& sb, hipStream_t st) 
         const bool first = p == 0, last = p + 1 == plan.n_passes;
         hipEvent_t e0 = profiling ? c->ev[EV_X0 + 2 * p] : samp_a[p];
         hipEvent_t e1 = profiling ? c->ev[EV_X0 + 2 * p + 1] : samp_b[p];
-        launch_pass<uint32_t, GSX_SORT_NT, GSX_SORT_IPT>(c, st, g, sb.keys[cur], first ? c->sel_idx : sb.vals[cur], sb.keys[cur ^ 1],
+        // (the last pass's keys are dead unless the gated pass sorts on their top bits: 4 B per key less to write)
+        launch_pass<uint32_t, GSX_SORT_NT, GSX_SORT_IPT>(c, st, g, sb.keys[cur], first ? c->sel_idx : sb.vals[cur],
+                                                          (last && !gated) ? nullptr : sb.keys[cur ^ 1],
                                                           last ? result : sb.vals[cur ^ 1], c->m_dev, plan.shift[p], plan.bits[p], sb.ws,
                                                           cols, /*need_hist=*/!first, /*iota=*/first && c->sel_iota, e0, e1);
         cur ^= 1;
