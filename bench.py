@@ -55,6 +55,7 @@ SCATTER_BYTES_PASS0 = 12        # k_radix_scatter<u32, iota>: read key (4 B), wr
 SCATTER_BYTES_PASSN = 16        # passes >= 1: read key + index (8 B), write key + index (8 B)
 KEYGEN_BYTES_PER_SPLAT = 20     # float4 position read + u32 key write (pass-0 digit count fused, no extra bytes)
 COUNT_BYTES_PER_SPLAT = 4       # k_radix_hist of passes >= 1: key read
+KEYGEN2_BYTES_PER_SPLAT = 16    # k2_keygen_hist: packed 12-byte position read + u32 key write (the 2-byte bucket counts ride along)
 PARTITION_BYTES = 12            # k2_partition: read key (4 B; the index is generated), write (key, index) pair (8 B)
 LOCAL_BYTES = 12                # k2_local: read pair (8 B), write index (4 B)
 BLEND_FLOP = 14                 # per pixel-splat blend: uv (5), r2 + scale (4), alpha (1), weight (1), 3 colour FMAs + T (4), 1 exp beside
@@ -64,7 +65,7 @@ SHADE_LDS_BYTES = 48            # per (wave, splat) visit: centre/extents, uv ma
 def sort_bytes_per_splat(passes, iota=True, form=1):
     """Algorithmic HBM bytes per splat of keys + sort."""
     if form == 2:       # keys + counts, partition, bucket sort (the count / prefix matrices add ~3 B per splat at 6 M: not counted)
-        return KEYGEN_BYTES_PER_SPLAT + PARTITION_BYTES + LOCAL_BYTES
+        return KEYGEN2_BYTES_PER_SPLAT + PARTITION_BYTES + LOCAL_BYTES
     if passes <= 0:
         return KEYGEN_BYTES_PER_SPLAT
     first = SCATTER_BYTES_PASS0 if iota else SCATTER_BYTES_PASSN
@@ -142,7 +143,7 @@ def kernel_rooflines_from_profile(n_splats):
     if not os.path.exists(path):
         return None
     bytes_per_call = {   # algorithmic bytes per launch at n_splats splats
-        "k2_keygen_hist": KEYGEN_BYTES_PER_SPLAT * n_splats,      # 16 B position in, 4 B key out (the 2-byte bucket counts ride along)
+        "k2_keygen_hist": KEYGEN2_BYTES_PER_SPLAT * n_splats,     # 12 B position in, 4 B key out (the 2-byte bucket counts ride along)
         "k2_partition": PARTITION_BYTES * n_splats,
         "k2_local<18>": None,                                       # (the two bucket-sort instances share the pairs: priced together below)
         "k2_local<8>": None,

@@ -56,7 +56,7 @@ int check_flags(gsx_ctx* c) {
 
 int alloc_scene(gsx_ctx* c, uint64_t n) {
     int rc;
-    if ((rc = dev_alloc(c, &c->pos4, n)) || (rc = dev_alloc(c, &c->geo, n))) return rc;
+    if ((rc = dev_alloc(c, &c->pos4, n)) || (rc = dev_alloc(c, &c->geo, n)) || (rc = dev_alloc(c, &c->pos3, n * 3))) return rc;
     if ((rc = dev_alloc(c, &c->sel_idx, n))) return rc;
     c->sel_cap = n;
     for (int b = 0; b < 2; ++b)
@@ -166,7 +166,7 @@ int gsx_destroy(gsx_ctx* c) {
     if (c->parked.fstream) (void)hipStreamSynchronize(c->parked.fstream);
     if (c->fstream) (void)hipStreamSynchronize(c->fstream);
     if (c->active_slot) gsx_slot_switch(c);          // slot 0 (the main stream's) back into the base
-    dev_free(&c->pos4); dev_free(&c->geo);
+    dev_free(&c->pos4); dev_free(&c->pos3); dev_free(&c->geo);
     dev_free(&c->sel_idx); dev_free(&c->m_dev); dev_free(&c->m_perm);
     dev_free(&c->lod_a); dev_free(&c->lod_b); dev_free(&c->lod_parent); dev_free(&c->lod_leaf); dev_free(&c->lod_child); dev_free(&c->lod_queue[0]); dev_free(&c->lod_queue[1]); dev_free(&c->lod_qcount); dev_free(&c->lod_top_anc);
     dev_free(&c->lod_stop); dev_free(&c->lod_emit); dev_free(&c->lod_block_sums);

@@ -194,7 +194,8 @@ struct gsx_ctx : GsxFrameSlot {
 
     // scene (SoA in HBM)
     uint64_t n = 0;
-    float4* pos4 = nullptr;    // transform[3] (x,y,z,w)
+    float4* pos4 = nullptr;    // transform[3] (x, y, z) + a conservative radius in w
+    float* pos3 = nullptr;     // x, y, z packed to 12 bytes: what the two-pass sort's key kernel streams
     GsxGeo* geo = nullptr;     // AoS twin for the per-rank gathers of the frame loop (pos4 stays SoA for the key pass)
 
     // selection

@@ -17,7 +17,7 @@
 // Upload: 80-B AoS `Splat` (Splat.h:19-29) -> SoA positions (key pass) + 64-B AoS records (frame loop).
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_upload_soa(const float4* __restrict__ aos, uint64_t n,
-                                                    float4* __restrict__ pos4, GsxGeo* __restrict__ geo,
+                                                    float4* __restrict__ pos4, float* __restrict__ pos3, GsxGeo* __restrict__ geo,
                                                     GsxDevFlags* __restrict__ flags) {
     const uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -47,6 +47,7 @@ __global__ __launch_bounds__(256) void k_upload_soa(const float4* __restrict__ a
         rho = (lmax >= 0.0f && lmax < 3.0e38f) ? sqrtf(lmax) * 1.0001f : __builtin_huge_valf();
     }
     pos4[i] = make_float4(pos.x, pos.y, pos.z, rho);
+    pos3[i * 3 + 0] = pos.x; pos3[i * 3 + 1] = pos.y; pos3[i * 3 + 2] = pos.z;     // the two-pass sort's key kernel reads 12 B per splat
     // column-major: c0 = (s00,s10,s20,_), c1 = (s01,s11,s21,_), c2 = (s02,s12,s22,_)
     float4* g = reinterpret_cast<float4*>(geo + i);
     g[0] = pos;
@@ -64,7 +65,7 @@ __global__ __launch_bounds__(256) void k_upload_soa(const float4* __restrict__ a
 int gsx_launch_upload(gsx_ctx* c, const void* aos80_dev, uint64_t n) {
     if (n == 0) return GSX_OK;
     hipLaunchKernelGGL(k_upload_soa, dim3(gsx_div_up(n, 256)), dim3(256), 0, c->stream,
-                       static_cast<const float4*>(aos80_dev), n, c->pos4, c->geo, c->flags);
+                       static_cast<const float4*>(aos80_dev), n, c->pos4, c->pos3, c->geo, c->flags);
     GSX_HIP(c, hipGetLastError());
     return GSX_OK;
 }
@@ -333,10 +334,10 @@ static int launch_sort_in(gsx_ctx* c, const GsxSortBuffers& sb, hipStream_t st) 
     if (p2.ok) {
         const Gsx2Workspace w = gsx2_ws_carve(c->s2_ws, c->sort_cap);
         if (c->sel_iota)
-            hipLaunchKernelGGL(k2_keygen_hist<true>, dim3(p2.ncols), dim3(GSX2_NT), 0, st, c->pos4, nullptr, c->m_dev, c->cam[0], c->cam[1],
+            hipLaunchKernelGGL(k2_keygen_hist<true>, dim3(p2.ncols), dim3(GSX2_NT), 0, st, reinterpret_cast<const Gsx2Pos*>(c->pos3), nullptr, c->m_dev, c->cam[0], c->cam[1],
                                c->cam[2], key_lo, key_span, p2.map, p2.nd, sb.keys[0], w.cnt, c->flags, sb.m_copy, w.stats);
         else
-            hipLaunchKernelGGL(k2_keygen_hist<false>, dim3(p2.ncols), dim3(GSX2_NT), 0, st, c->pos4, c->sel_idx, c->m_dev, c->cam[0], c->cam[1],
+            hipLaunchKernelGGL(k2_keygen_hist<false>, dim3(p2.ncols), dim3(GSX2_NT), 0, st, reinterpret_cast<const Gsx2Pos*>(c->pos3), c->sel_idx, c->m_dev, c->cam[0], c->cam[1],
                                c->cam[2], key_lo, key_span, p2.map, p2.nd, sb.keys[0], w.cnt, c->flags, sb.m_copy, w.stats);
         if (profiling) GSX_HIP(c, hipEventRecord(c->ev[EV_KEY1], st));
         hipLaunchKernelGGL(k2_scan, dim3(p2.nd / 16), dim3(512), 0, st, w.cnt, w.pre, w.totals, p2.nd, p2.ncols);

@@ -76,8 +76,9 @@ __host__ __device__ __forceinline__ uint32_t gsx2_bucket_bits(uint32_t d, const 
 
 // ---- A: keys + per-column counts of the top digit ------------------------------------------------------------
 // cnt[col * nd + d], 2-byte counts (a column holds at most GSX2_COLMAX keys).  Grid = number of columns.
+struct Gsx2Pos { float x, y, z; };       // 12-byte position record of the key pass (a wave's loads cover 768 contiguous bytes)
 template <bool IOTA>
-__global__ __launch_bounds__(GSX2_NT) void k2_keygen_hist(const float4* __restrict__ pos4, const uint32_t* __restrict__ sel,
+__global__ __launch_bounds__(GSX2_NT) void k2_keygen_hist(const Gsx2Pos* __restrict__ pos3, const uint32_t* __restrict__ sel,
                                                           const uint32_t* __restrict__ m_ptr, float cx, float cy, float cz, uint32_t key_lo,
                                                           uint32_t key_span, Gsx2Map mp, uint32_t nd,
                                                           uint32_t* __restrict__ keys, uint16_t* __restrict__ cnt, GsxDevFlags* __restrict__ flags,
@@ -94,19 +95,19 @@ __global__ __launch_bounds__(GSX2_NT) void k2_keygen_hist(const float4* __restri
     gsx_block_range(m, gridDim.x, col, begin, end);
     constexpr int UNROLL = 4;
     for (uint32_t base = begin + threadIdx.x; base < end; base += GSX2_NT * UNROLL) {
-        float4 p[UNROLL];
+        Gsx2Pos p[UNROLL];
         bool ok[UNROLL];
 #pragma unroll
         for (int j = 0; j < UNROLL; ++j) {
             const uint32_t k = base + j * GSX2_NT;
             ok[j] = k < end;
-            if (ok[j]) p[j] = pos4[IOTA ? k : sel[k]];
+            if (ok[j]) p[j] = pos3[IOTA ? k : sel[k]];
         }
 #pragma unroll
         for (int j = 0; j < UNROLL; ++j) {
             if (!ok[j]) continue;
             const uint32_t k = base + j * GSX2_NT;
-            const uint32_t key = gsx_key_from_distance(gsx_distance(p[j], cx, cy, cz));
+            const uint32_t key = gsx_key_from_distance(gsx_distance(make_float4(p[j].x, p[j].y, p[j].z, 0.0f), cx, cy, cz));
             uint32_t rel = key - key_lo;
             if (key < key_lo || rel > key_span) {   // outside the bound: NaN/inf position
                 atomicOr(&flags->key_bound, 1u);

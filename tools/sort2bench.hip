@@ -55,7 +55,7 @@ int main(int argc, char** argv) {
            plan.nd, plan.idx_bits, plan.ncols);
     if (!plan.ok) return 2;
     hipStream_t st; CK(hipStreamCreate(&st));
-    float4* d_pos; uint32_t *d_keys, *d_m, *d_pre, *d_tot, *d_base, *d_res, *d_keys_out; uint16_t* d_cnt; uint2 *d_pairs, *d_scratch;
+    float4* d_pos; Gsx2Pos* d_pos3; uint32_t *d_keys, *d_m, *d_pre, *d_tot, *d_base, *d_res, *d_keys_out; uint16_t* d_cnt; uint2 *d_pairs, *d_scratch;
     GsxDevFlags* d_flags; Gsx2Stats* d_stats;
     CK(hipMalloc(&d_pos, (size_t)n * 16)); CK(hipMalloc(&d_keys, (size_t)n * 4)); CK(hipMalloc(&d_m, 4));
     CK(hipMalloc(&d_cnt, (size_t)GSX2_MAX_COLS * GSX2_MAX_D * 2)); CK(hipMalloc(&d_pre, (size_t)GSX2_MAX_COLS * GSX2_MAX_D * 4));
@@ -63,12 +63,17 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&d_pairs, (size_t)n * 8)); CK(hipMalloc(&d_scratch, (size_t)n * 8));
     CK(hipMalloc(&d_flags, sizeof(GsxDevFlags))); CK(hipMalloc(&d_stats, sizeof(Gsx2Stats)));
     CK(hipMemset(d_flags, 0, sizeof(GsxDevFlags))); CK(hipMemset(d_stats, 0, sizeof(Gsx2Stats)));
-    CK(hipMemcpy(d_pos, pos.data(), (size_t)n * 16, hipMemcpyHostToDevice)); CK(hipMemcpy(d_m, &n, 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(d_pos, pos.data(), (size_t)n * 16, hipMemcpyHostToDevice));
+    {   // the library's key kernel streams packed 12-byte positions
+        std::vector<float> p3((size_t)n * 3);
+        for (size_t i = 0; i < (size_t)n; ++i) { p3[3 * i] = pos[i].x; p3[3 * i + 1] = pos[i].y; p3[3 * i + 2] = pos[i].z; }
+        CK(hipMalloc(&d_pos3, (size_t)n * 12)); CK(hipMemcpy(d_pos3, p3.data(), (size_t)n * 12, hipMemcpyHostToDevice));
+    } CK(hipMemcpy(d_m, &n, 4, hipMemcpyHostToDevice));
     hipEvent_t ev[7]; for (int k = 0; k < 7; ++k) CK(hipEventCreate(&ev[k]));
     std::vector<float> t[7];
     for (int rep = 0; rep < reps + 3; ++rep) {
         CK(hipEventRecord(ev[0], st));
-        hipLaunchKernelGGL(k2_keygen_hist<true>, dim3(plan.ncols), dim3(GSX2_NT), 0, st, d_pos, nullptr, d_m, cx, cy, cz, key_lo, key_span, plan.map, plan.nd,
+        hipLaunchKernelGGL(k2_keygen_hist<true>, dim3(plan.ncols), dim3(GSX2_NT), 0, st, d_pos3, nullptr, d_m, cx, cy, cz, key_lo, key_span, plan.map, plan.nd,
                            d_keys, d_cnt, d_flags, nullptr, d_stats);
         CK(hipEventRecord(ev[1], st));
         hipLaunchKernelGGL(k2_scan, dim3(plan.nd / 16), dim3(512), 0, st, d_cnt, d_pre, d_tot, plan.nd, plan.ncols);
