@@ -74,11 +74,21 @@ def cfg3():
         for f in range(10):
             g.select_octree(poses[f][2], 0.002, want_count=False); g.sort(poses[f][1], download=False); g.render(poses[f][0], W, H, download=False)
         g.sync()
+        ahead = os.environ.get("GSX_AHEAD", "") != ""         # GSX_AHEAD=1: cut + sort of frame f+1 queued before frame f (option sort_ahead); measured: 0.401 against 0.395 ms here
+        if ahead:
+            g.set_option("sort_ahead", 1)
+            g.select_octree(poses[0][2], 0.002, want_count=False)
+            g.sort(poses[0][1], download=False)
         t0 = time.perf_counter()
         for f in range(frames):
             u, pos, vp = poses[f]
-            g.select_octree(vp, 0.002, want_count=False)
-            g.sort(pos, download=False)
+            if ahead:
+                _, npos, nvp = poses[(f + 1) % frames]
+                g.select_octree(nvp, 0.002, want_count=False)
+                g.sort(npos, download=False)
+            else:
+                g.select_octree(vp, 0.002, want_count=False)
+                g.sort(pos, download=False)
             g.render(u, W, H, download=False)
         g.sync()
         dt = (time.perf_counter() - t0) / frames
@@ -86,6 +96,7 @@ def cfg3():
     emit({"config": "cfg3", "splats": n, "octree_nodes": int(tree.n), "host_octree_build_s": build_s, "frames": frames,
           "what": "octree cut (threshold 0.002) -> sort -> 1080p frame per orbit step", "cut_sizes_at_frames_0_30_60_90": ms,
           "ms_per_frame": dt * 1e3, "fps": 1.0 / dt, "last_frame_tile_pairs": t["tile_pairs"], "last_frame_iters": t["render_iters"],
+          "call_order": "cut + sort f+1, render f (sort_ahead)" if ahead else "cut, sort, render f",
           "opts": os.environ.get("GSX_OPTS", "")})
     tree.close()
 
@@ -100,10 +111,16 @@ def cfg4():
         for o in os.environ.get("GSX_OPTS", "").split():      # A/B runs: GSX_OPTS="no_history=1 chunk_first=262144"
             k, val = o.split("=")
             g.set_option(k, int(val))
+        ahead = os.environ.get("GSX_AHEAD", "") != ""
+        if ahead:
+            g.set_option("sort_ahead", 1)
         for rnd in range(2):
+            if ahead:
+                g.set_option("sort_ahead", 1)                  # (forgets what waits from the round before)
+                g.sort(views[0][2], download=False)
             t0 = time.perf_counter()
             for i, v in enumerate(views):
-                g.sort(v[2], download=False)
+                g.sort(views[(i + 1) % len(views)][2] if ahead else v[2], download=False)
                 g.render(us[i], W, H, download=False)
             g.sync()
             dt = (time.perf_counter() - t0) / len(views)
