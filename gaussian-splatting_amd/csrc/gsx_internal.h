@@ -250,6 +250,8 @@ struct gsx_ctx : GsxFrameSlot {
     bool s2_stats_rec = false;
     uint32_t s2_stats_tick = 0;
     uint32_t s2_backoff = 0, s2_backoff_len = 0;   // sorts left on the LSD passes after a sort that sent many keys through k2_big / length of the next pause
+    uint32_t s2_hint_scale = 1;
+    uint32_t s2_m_hint = 0, s2_hint_cap = 0;   // selection size seen by a recent two-pass sort (x 1.5) and the capacity it was seen under: sizes the bucket count
     uint64_t opt_sort_algo = 0;                    // 0 automatic, 1 LSD passes only, 2 two-pass whenever its plan allows (any size)
     bool sort_two_pass = false;                    // the latest depth sort ran the two-pass form
     uint32_t sort_launches = 0;

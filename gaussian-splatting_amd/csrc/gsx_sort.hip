@@ -283,15 +283,27 @@ static int launch_sort_in(gsx_ctx* c, const GsxSortBuffers& sb, hipStream_t st) 
     if (sb.two_pass_ok && c->s2_pairs && c->opt_sort_algo != 1) {
         if (c->s2_stats_rec && hipEventQuery(c->ev_s2_stats) == hipSuccess) {
             c->s2_stats_rec = false;
-            if (g_dbg_sort2) fprintf(stderr, "[gsx] two-pass stats: big_buckets %u big_keys %u max_bucket %u (cap %u)\n", c->s2_stats_host->big_buckets, c->s2_stats_host->big_keys, c->s2_stats_host->max_bucket, cap);
-            if (static_cast<uint64_t>(c->s2_stats_host->big_keys) * 64ull > cap) {
-                c->s2_backoff_len = c->s2_backoff_len ? (c->s2_backoff_len < 512u ? c->s2_backoff_len * 2u : 1024u) : 16u;
-                c->s2_backoff = c->s2_backoff_len;
-            } else if (c->s2_stats_host->big_keys == 0) {
-                c->s2_backoff_len = 0;
+            if (g_dbg_sort2) fprintf(stderr, "[gsx] two-pass stats: big_buckets %u big_keys %u max_bucket %u keys %u (cap %u)\n", c->s2_stats_host->big_buckets, c->s2_stats_host->big_keys, c->s2_stats_host->max_bucket, c->s2_stats_host->keys, cap);
+            // the size of that selection sizes the next sorts' buckets (a cut's size never reaches the host otherwise); buckets that
+            // overflowed although the hint was below the capacity mean the selection has grown: forget the hint
+            const uint32_t seen = c->s2_stats_host->keys;
+            const bool hinted = c->s2_hint_cap == cap && c->s2_m_hint != 0 && c->s2_m_hint < cap;
+            if (c->s2_stats_host->big_keys != 0 && hinted) {
+                c->s2_m_hint = 0;
+                if (c->s2_hint_scale < 64u) c->s2_hint_scale *= 2u;         // (or the scene is denser than its size says: size the buckets for more)
+            } else {
+                if (static_cast<uint64_t>(c->s2_stats_host->big_keys) * 64ull > cap) {
+                    c->s2_backoff_len = c->s2_backoff_len ? (c->s2_backoff_len < 512u ? c->s2_backoff_len * 2u : 1024u) : 16u;
+                    c->s2_backoff = c->s2_backoff_len;
+                } else if (c->s2_stats_host->big_keys == 0) {
+                    c->s2_backoff_len = 0;
+                }
+                const uint64_t want = (static_cast<uint64_t>(seen) + seen / 2u) * c->s2_hint_scale;   // (half as much again: cuts along an orbit vary by ~20 %)
+                c->s2_m_hint = want < cap ? static_cast<uint32_t>(want) : cap;
+                c->s2_hint_cap = cap;
             }
         }
-        p2 = gsx2_plan(key_span, cap, c->n, 0, c->opt_sort_algo == 2);
+        p2 = gsx2_plan(key_span, cap, c->n, 0, c->opt_sort_algo == 2, c->s2_hint_cap == cap ? c->s2_m_hint : 0u);
         if (p2.ok && c->opt_sort_algo == 0 && c->s2_backoff) { --c->s2_backoff; p2.ok = false; }
     }
     const bool gated = top_bits != 0 && !p2.ok;      // (the two-pass form orders all 31 key bits itself: its buckets widen towards the camera)

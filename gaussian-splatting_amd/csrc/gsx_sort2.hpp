@@ -41,7 +41,7 @@ struct Gsx2Stats {
     uint32_t big_buckets;    // buckets larger than GSX2_CAP in the latest sort (k2_partition, block 0)
     uint32_t big_keys;       // keys in them
     uint32_t max_bucket;
-    uint32_t reserved;
+    uint32_t keys;           // selection size of that sort (a cut's size is known only on the device: the next plan sizes its buckets by it)
 };
 
 // Bucket of a (relative) key.  Keys are inverted float bit patterns, so 2^23 consecutive key values span a factor of two in
@@ -247,7 +247,7 @@ __global__ __launch_bounds__(GSX2_PNT) void k2_partition(const uint32_t* __restr
         atomicMax(&s_big[2], mx);
     }
     __syncthreads();
-    if (col == 0 && tid == 0) { stats->big_buckets = s_big[0]; stats->big_keys = s_big[1]; stats->max_bucket = s_big[2]; }
+    if (col == 0 && tid == 0) { stats->big_buckets = s_big[0]; stats->big_keys = s_big[1]; stats->max_bucket = s_big[2]; stats->keys = m; }
 #pragma unroll
     for (int j = 0; j < GSX2_KPT; ++j) {
         const uint32_t k = begin + j * GSX2_PNT + tid;
@@ -551,14 +551,19 @@ static inline uint32_t gsx2_cols_for(uint64_t m_cap) {
 }
 
 // key_span: largest relative key of the frame (host bound); m_cap: host bound of the selection size; ids are < n_ids.
-static inline Gsx2Plan gsx2_plan(uint32_t key_span, uint32_t m_cap, uint64_t n_ids, uint32_t t_force = 0, bool any_size = false) {
+// m_hint (0 = none): what the selection is expected to hold - the number of BUCKETS follows it (a cut of 1.1 M nodes out of a
+// tree of 8.5 M wants ~1 K buckets, not 8 K: every workgroup of the partition initialises tables of that length); the number of
+// COLUMNS always follows m_cap, because a column must hold its share of whatever the selection turns out to be.
+static inline Gsx2Plan gsx2_plan(uint32_t key_span, uint32_t m_cap, uint64_t n_ids, uint32_t t_force = 0, bool any_size = false,
+                                 uint32_t m_hint = 0) {
     Gsx2Plan p;
     if (key_span > 0x7FFFFFFFu) return p;
     const uint32_t fine_span = key_span < (1u << 25) ? key_span : (1u << 25) - 1u;
     uint32_t bits = 0;
     while ((fine_span >> bits) != 0) ++bits;
     uint32_t t = 10;
-    while (t < GSX2_MAX_T - 1 && (1536ull << t) < m_cap) ++t;    // ~1.5 K keys per bucket if they were spread evenly over the fine region
+    const uint32_t m_for_t = (m_hint && m_hint < m_cap) ? m_hint : m_cap;
+    while (t < GSX2_MAX_T - 1 && (1536ull << t) < m_for_t) ++t;  // ~1.5 K keys per bucket if they were spread evenly over the fine region
     if (t_force) t = t_force;
     if (bits < t + 5) return p;                                   // narrow key range: the LSD passes are as good
     if (m_cap < (1u << 17) && !any_size) return p;                // small sorts are launch-bound either way
