@@ -173,6 +173,48 @@ def test_two_pass_on_a_selection_list(gsx_fresh, oracle, synth):
         assert gsx.timings()["sort_passes"] == 2
 
 
+def test_two_pass_bucket_count_follows_the_cut_size(gsx_fresh, oracle, synth):
+    """The two-pass sort sizes its buckets by the selection size recent sorts saw (a device-side cut's size never reaches the
+    host otherwise).  A cut that jumps from one node to 262 144 nodes lying in a thin depth shell meets a plan sized for the
+    small cut: buckets overflow LDS, the slow path sorts them, the hint is dropped - and every permutation is still exact."""
+    gsx = gsx_fresh
+    levels = 7
+    starts = np.cumsum([0] + [8 ** l for l in range(levels)])
+    n = int(starts[-1])                                          # 299 593 nodes, 262 144 of them leaves
+    parent = np.full(n, 0xFFFFFFFF, np.uint32)
+    for l in range(1, levels):
+        j = np.arange(8 ** l)
+        parent[starts[l] + j] = starts[l - 1] + j // 8
+    leaf = np.zeros(n, np.uint8)
+    leaf[starts[levels - 1]:] = 1
+    rng = np.random.Generator(np.random.PCG64(11))
+    splats = oracle.raw_to_splat(synth.uniform_cloud(n, seed=21)).copy()
+    flat = splats.reshape(n, -1)
+    assert flat.shape[1] == 20
+    cam = np.array([0.3, -0.2, 0.1], np.float32)
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    radius = (4.0 + 1.0e-4 * rng.random(n)).astype(np.float32)   # a shell 0.1 mm thick: a few hundred distinct keys, many ties
+    flat[:, 12:15] = cam + d * radius[:, None]
+    center3 = np.zeros((n, 3), np.float32)
+    half3 = np.full((n, 3), 50.0, np.float32)
+    gsx.set_option("sort_algo", 2)
+    gsx.upload(splats)
+    gsx.set_lod_octree(center3, half3, parent, leaf)
+    vp = np.eye(4, dtype=np.float32).reshape(-1)
+    leaves = np.arange(starts[levels - 1], n, dtype=np.uint32)
+    big = oracle.sort_contract(splats, cam, leaves)
+    one = oracle.sort_contract(splats, cam, np.zeros(1, np.uint32))
+    for rep in range(2):
+        for k in range(9):                                       # the root stops: one node (statistics reach the host every 4th sort)
+            assert gsx.select_octree(vp, 1.0e30) == 1
+            assert np.array_equal(gsx.sort(cam), one)
+        for k in range(9):                                       # nothing stops before the leaves
+            gsx.select_octree(vp, -1.0, want_count=False)
+            assert np.array_equal(gsx.sort(cam), big), f"round {rep}, sort {k} after the jump"
+            assert gsx.timings()["sort_form"] == 2
+
+
 def test_sort_is_repeatable_and_view_dependent(gsx, oracle, synth):
     splats = oracle.raw_to_splat(synth.clustered_cloud(30000, seed=8))
     gsx.upload(splats)
