@@ -17,7 +17,7 @@ root = sys.argv[1]
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 6_000_000
 cal_bytes = 96 << 20
 groups = {"k2_keygen_hist": "k2_keygen_hist", "k2_scan": "k2_scan", "k2_partition": "k2_partition", "k2_local": "k2_local"}
-alg = {"k2_keygen_hist": 20 * n, "k2_scan": None, "k2_partition": 12 * n, "k2_local": 12 * n}
+alg = {"k2_keygen_hist": 16 * n, "k2_scan": None, "k2_partition": 12 * n, "k2_local": 12 * n}
 res = {"splats": n, "calibration_bytes": cal_bytes, "kernels": {g: {"algorithmic_bytes": alg[g]} for g in groups}, "scale": {}}
 for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
     cal4, _ = per_kernel(os.path.join(root, "cal4_" + ctr))
