@@ -107,21 +107,21 @@ const char* gsx_last_error(const gsx_ctx* ctx);
 int gsx_sync(gsx_ctx* ctx);
 /* 0 = no events (default).  1 = HIP events around every stage and every radix scatter launch
  * (gsx_get_timings fills all *_ms fields; the ~20 events cost tens of microseconds per frame).
- * 2 = sampled: in every 8th sort (option "sample_every") ONE thing is bracketed, rotating: the k_radix_scatter launch of pass 0, 1, ... of the
- * depth sort (scatter_ms = the latest such launch, scatter_sample says which pass), then keys + sort as a whole.  A sampled
- * sort runs on the main stream instead of beside the previous frame (see gsx_sort), so the bracket times the kernel, not
- * its share of a GPU it splits with the rasterizer.  The samples go through a ring of event pairs, so frames can be queued
- * back to back without reading anything in between; gsx_get_scatter_samples returns what has accumulated. */
-/* With the two-pass form of the depth sort (gsx_timings.sort_form == 2) the "passes" a sample brackets are 0 = the partition
- * kernel and 1 = the bucket-sort kernels. */
+ * 2 = sampled: every 8th sort (option "sample_every") carries events, alternately (a) one pair around every HBM pass of the
+ * sort - the k_radix_scatter launches of the LSD form, or the partition kernel and the bucket-sort kernels of the two-pass form
+ * (gsx_timings.sort_form == 2: "pass" 0 and 1) - and (b) one pair around keys + sort as a whole (scatter_ms = the latest
+ * sampled launch, scatter_sample says which pass).  A sampled sort runs on the main stream behind every queued frame, and what
+ * is queued on the context's other streams while it runs starts behind it, so the brackets time the kernels themselves, not
+ * their share of a GPU they split with the rasterizer.  The samples go through a ring of event pairs, so frames can be queued
+ * back to back without reading anything in between; gsx_get_scatter_samples / gsx_get_sort_samples return what has accumulated. */
 int gsx_set_profiling(gsx_ctx* ctx, int enabled);
 int gsx_get_timings(gsx_ctx* ctx, gsx_timings* out);
 /* Profiling level 2 (no counterpart in the reference): per radix pass p < 4 of the depth sort, the summed
  * duration (ms) and the number of sampled k_radix_scatter launches since the last reset.  Waits for the
  * queued work like gsx_get_timings; reset != 0 clears the sums. */
 int gsx_get_scatter_samples(gsx_ctx* ctx, double sum_ms[4], uint32_t launches[4], int reset);
-/* Profiling level 2 also brackets keys + sort AS A WHOLE (from before the key kernel to behind the last radix pass) in
- * every (passes + 1)-th SAMPLED sort of the rotation: summed duration (ms) and number of such sorts since the last reset. */
+/* Profiling level 2 also brackets keys + sort AS A WHOLE (from before the key kernel to behind the last pass) in
+ * every second SAMPLED sort: summed duration (ms) and number of such sorts since the last reset. */
 int gsx_get_sort_samples(gsx_ctx* ctx, double* sum_ms, uint32_t* sorts, int reset);
 /* Tuning knobs of the frame loop (no counterpart in the reference; 0 restores the default):
  *   "pair_budget"   (tile, splat) pairs one near -> far iteration may emit (sizes the pair buffers,
