@@ -171,6 +171,15 @@ def test_two_pass_on_a_selection_list(gsx_fresh, oracle, synth):
     for cam in CAMS[:2]:
         assert np.array_equal(gsx.sort(cam), oracle.sort_contract(splats, cam, ids))
         assert gsx.timings()["sort_passes"] == 2
+    # an empty selection and a single splat go through the same five launches
+    gsx.select_list(np.zeros(0, np.uint32))
+    assert len(gsx.sort(CAMS[0])) == 0
+    gsx.select_list(np.array([n - 1], np.uint32))
+    assert np.array_equal(gsx.sort(CAMS[1]), np.array([n - 1], np.uint32))
+    gsx.select_list(ids[:70])                                  # (a bucket of at most 64 pairs is ranked by one wave)
+    assert np.array_equal(gsx.sort(CAMS[1]), oracle.sort_contract(splats, CAMS[1], ids[:70]))
+    gsx.select_all()
+    assert np.array_equal(gsx.sort(CAMS[0]), oracle.sort_contract(splats, CAMS[0]))
 
 
 def test_two_pass_bucket_count_follows_the_cut_size(gsx_fresh, oracle, synth):
