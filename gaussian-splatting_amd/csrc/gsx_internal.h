@@ -234,9 +234,9 @@ struct gsx_ctx : GsxFrameSlot {
     uint64_t sort_ws_words = 0;
     uint32_t* host_word = nullptr;     // pinned staging word(s) for small device->host reads
     bool sorted_valid = false;
-    // The last radix pass writes into perm[perm_cur ^ 1] and then flips perm_cur: a frame still in flight (and any
-    // continuation iterations gsx_frame_finish queues for it later) keeps reading the other buffer, so the next
-    // frame's sort can be queued without waiting for the previous frame.
+    // The sort's last kernel writes into perm[(perm_cur + 1) % GSX_PERM_RING] and perm_cur then moves on: the frames still in
+    // flight (and any continuation iterations gsx_frame_finish queues for them later) keep reading their own buffers, so the
+    // next frame's sort can be queued without waiting for them.
     uint32_t* perm[GSX_PERM_RING] = {};
     uint32_t perm_cur = 0;             // perm[perm_cur] holds the latest permutation; the next sort writes perm[(perm_cur + 1) % GSX_PERM_RING]
     uint32_t* m_perm = nullptr;        // GSX_PERM_RING device words: size of the selection each permutation was sorted from

@@ -473,7 +473,7 @@ int gsx_launch_sort(gsx_ctx* c) {
                 if (sl->frame_pending && sl->fstream != c->stream) GSX_HIP(c, hipStreamWaitEvent(c->stream, sl->frame_ev, 0));
         }
     }
-    // the last frame that drew from the buffer this sort overwrites (three buffers: the frame before the two that may be in flight)
+    // the last frame that drew from the buffer this sort overwrites (four buffers: older than the two frames that may be in flight and the permutation that may wait to be drawn)
     if (c->frame_done_rec[target]) GSX_HIP(c, hipStreamWaitEvent(st, c->ev_frame_done[target], 0));
     const int rc = launch_sort_in(c, sb, st);
     if (rc != GSX_OK) return rc;
