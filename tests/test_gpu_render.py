@@ -792,7 +792,7 @@ def test_tile_rank_caps_same_pixels_fewer_pairs_and_redo(gsx_fresh, pkg, oracle,
     assert gsx.timings()["render_capped"] == 0
 
 
-@pytest.mark.parametrize("seed", [1, 2, 3])
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
 def test_random_call_sequences_match_the_strict_order(pkg, oracle, synth, seed):
     """Two contexts get the same random sequence of calls - selections (all / list / octree cut), sorts and frames with and
     without read-back, tile bands, render targets, option changes, syncs.  One runs with everything the library overlaps or
@@ -811,6 +811,9 @@ def test_random_call_sequences_match_the_strict_order(pkg, oracle, synth, seed):
             tree.upload(g)
         for k, v in (("async_sort", 0), ("frames_in_flight", 1), ("tile_caps", 0), ("no_history", 1)):
             strict.set_option(k, v)
+        if seed == 4:                        # the two forms of the depth sort against each other (cuts and lists of any size)
+            fast.set_option("sort_algo", 2)
+            strict.set_option("sort_algo", 1)
         poses = []
         for f in range(6):
             world, _ = oracle.orbit_world(4.0, (0.0, 1.0, 0.0), 0.004, f)          # a slow orbit: the rank caps stay in play
@@ -863,5 +866,67 @@ def test_random_call_sequences_match_the_strict_order(pkg, oracle, synth, seed):
             assert np.array_equal(fast.sort(cam), strict.sort(cam))
             assert np.array_equal(fast.render(u, w, h), strict.render(u, w, h))
         assert frames >= 10 and perms >= 5, (frames, perms)
+    finally:
+        fast.close(); strict.close(); tree.close()
+
+
+@pytest.mark.parametrize("seed", [11, 12])
+def test_random_call_sequences_with_sort_ahead(pkg, oracle, synth, seed):
+    """Option sort_ahead under random call sequences: `fast` queues sorts ahead of frames (up to two permutations wait, a third
+    sort drops the oldest, gsx_render draws the oldest), `strict` runs in order with everything else switched off and is told
+    which camera each frame belongs to.  Every frame read back must agree byte for byte."""
+    import importlib
+    lodm = importlib.import_module("gaussian_splatting_amd.lod")
+    rng = np.random.default_rng(seed)
+    w, h = 320, 208
+    tree = lodm.build_octree(synth.clustered_cloud(150_000, seed=seed))
+    n = tree.n
+    fast, strict = pkg.Gsx(0), pkg.Gsx(0)
+    try:
+        for g in (fast, strict):
+            tree.upload(g)
+        for k, v in (("async_sort", 0), ("frames_in_flight", 1), ("tile_caps", 0), ("no_history", 1), ("sort_algo", 1)):
+            strict.set_option(k, v)
+        fast.set_option("sort_algo", 2 if seed % 2 else 0)
+        fast.set_option("sort_ahead", 1)
+        poses = []
+        for f in range(8):
+            world, _ = oracle.orbit_world(4.0, (0.0, 1.0, 0.0), 0.02, f)
+            view, proj, vp, cam = oracle.camera(world, 45.0, w / h)
+            poses.append((pkg.make_uniforms(proj, view), cam, vp))
+        waiting, latest, frames = [], None, 0            # poses whose permutation waits to be drawn in `fast`; the latest sort
+        for step in range(300):
+            op = rng.choice(["sort"] * 8 + ["render"] * 8 + ["sel_all", "sel_list", "sel_oct", "sync", "prof"])
+            k = int(rng.integers(0, len(poses)))
+            if op == "sort":
+                fast.sort(poses[k][1], download=False)
+                latest = k
+                waiting = (waiting + [k])[-2:]
+            elif op == "render" and latest is not None:
+                draw = waiting.pop(0) if waiting else latest
+                u, cam, _ = poses[draw]
+                strict.sort(cam, download=False)
+                if rng.random() < 0.5:
+                    a, b = fast.render(u, w, h), strict.render(u, w, h)
+                    assert np.array_equal(a, b), (step, draw)
+                    frames += 1
+                else:
+                    fast.render(u, w, h, download=False); strict.render(u, w, h, download=False)
+            elif op in ("sel_all", "sel_list", "sel_oct"):
+                if op == "sel_all":
+                    fast.select_all(); strict.select_all()
+                elif op == "sel_list":
+                    idx = rng.choice(n, size=int(rng.integers(1, n)), replace=False).astype(np.uint32)
+                    fast.select_list(idx); strict.select_list(idx)
+                else:
+                    thr = float(rng.choice([0.002, 0.0005, 0.02]))
+                    fast.select_octree(poses[k][2], thr, want_count=False); strict.select_octree(poses[k][2], thr, want_count=False)
+                fast.set_option("sort_ahead", 1)            # a new selection: forget the permutations of the old one
+                waiting, latest = [], None
+            elif op == "sync":
+                fast.sync(); strict.sync()
+            elif op == "prof":
+                fast.set_profiling(int(rng.choice([0, 0, 2])))
+        assert frames >= 20, frames
     finally:
         fast.close(); strict.close(); tree.close()
