@@ -393,8 +393,8 @@ def test_scatter_slot_options_change_nothing(gsx_fresh, pkg, oracle, synth):
 
 
 def test_large_render_properties(gsx_fresh, pkg, oracle, synth):
-    """cfg-2 size (6M splats, 1920x1080): the image oracle would take minutes, so check size-independent
-    properties of the frame loop instead."""
+    """cfg-2 size (6M splats, 1920x1080): the image oracle would take minutes for the whole frame, so check size-independent
+    properties of the frame loop, and the oracle on one 64-row band of it."""
     gsx = gsx_fresh
     n, w, h = 6_000_000, 1920, 1080
     splats = oracle.raw_to_splat(synth.clustered_cloud(n, seed=6))
@@ -428,6 +428,12 @@ def test_large_render_properties(gsx_fresh, pkg, oracle, synth):
     near = gsx.render(u, w, h)
     assert np.array_equal(near, img)
     gsx.select_all()
+    # (4b) the image oracle at FULL size on a band of the frame: rows 508 .. 572 of the 1080p picture (four tile rows) with all 6 M splats
+    #      (the oracle projects every splat and rasterizes the band's rows: ~10 s of CPU)
+    yb0, yb1 = 508, 572
+    ref_band = oracle.render(splats, perm, orc.make_uniforms(proj, view), w, h, yb0, yb1)
+    assert ref_band[yb0:yb1, :, :3].std() > 5
+    check_image(img[yb0:yb1], ref_band[yb0:yb1])
     # (5) with the history-based schedule (default) frames are byte-identical to the history-free frame
     gsx.set_option("no_history", 0)
     gsx.sort(cam)
