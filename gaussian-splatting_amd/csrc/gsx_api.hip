@@ -43,13 +43,15 @@ int check_flags(gsx_ctx* c) {
     if (frc) return frc;
     GSX_HIP(c, hipMemcpyAsync(c->flags_host, c->flags, sizeof(GsxDevFlags), hipMemcpyDeviceToHost, c->stream));
     GSX_HIP(c, hipStreamSynchronize(c->stream));
-    const bool bad_index = c->flags_host->bad_index != 0, key_bound = c->flags_host->key_bound != 0;
-    if (bad_index || key_bound) {
+    const bool bad_index = c->flags_host->bad_index != 0, key_bound = c->flags_host->key_bound != 0, lod_fault = c->flags_host->lod_fault != 0;
+    if (bad_index || key_bound || lod_fault) {
         // reported once: the words are cleared so that the next (valid) selection / sort on this context succeeds
-        static_assert(offsetof(GsxDevFlags, key_bound) == offsetof(GsxDevFlags, bad_index) + 4, "bad_index and key_bound are adjacent");
-        GSX_HIP(c, hipMemsetAsync(&c->flags->bad_index, 0, 8, c->stream));
+        static_assert(offsetof(GsxDevFlags, key_bound) == offsetof(GsxDevFlags, bad_index) + 4 && offsetof(GsxDevFlags, lod_fault) == offsetof(GsxDevFlags, bad_index) + 8,
+                      "bad_index, key_bound and lod_fault are adjacent");
+        GSX_HIP(c, hipMemsetAsync(&c->flags->bad_index, 0, 12, c->stream));
     }
     if (bad_index) { c->err = "selection list holds an id >= n"; return GSX_E_INVALID; }
+    if (lod_fault) { c->err = "device: the selection's compaction or the octree walk did not complete (lod_fault)"; return GSX_E_INTERNAL; }
     if (key_bound) { c->err = "device: a depth key left the scene's distance bound (non-finite position?)"; return GSX_E_INTERNAL; }
     return GSX_OK;
 }
@@ -75,6 +77,9 @@ int alloc_scene(gsx_ctx* c, uint64_t n) {
     const uint64_t fl = (n + 15) / 16 * 16 + 16;
     if ((rc = dev_alloc(c, &c->lod_stop, fl)) || (rc = dev_alloc(c, &c->lod_emit, fl))) return rc;
     if ((rc = dev_alloc(c, &c->lod_block_sums, n / 4096 + 2))) return rc;
+    if ((rc = dev_alloc(c, &c->lod_agg, 512))) return rc;
+    GSX_HIP(c, hipMemset(c->lod_agg, 0, 512 * sizeof(uint64_t)));
+    c->lod_seq = 0;
     c->lod_cap = n;
     return GSX_OK;
 }
@@ -169,7 +174,7 @@ int gsx_destroy(gsx_ctx* c) {
     dev_free(&c->pos4); dev_free(&c->pos3); dev_free(&c->geo);
     dev_free(&c->sel_idx); dev_free(&c->m_dev); dev_free(&c->m_perm);
     dev_free(&c->lod_a); dev_free(&c->lod_b); dev_free(&c->lod_parent); dev_free(&c->lod_leaf); dev_free(&c->lod_child); dev_free(&c->lod_queue[0]); dev_free(&c->lod_queue[1]); dev_free(&c->lod_qcount); dev_free(&c->lod_top_anc);
-    dev_free(&c->lod_stop); dev_free(&c->lod_emit); dev_free(&c->lod_block_sums);
+    dev_free(&c->lod_stop); dev_free(&c->lod_emit); dev_free(&c->lod_block_sums); dev_free(&c->lod_agg);
     for (int b = 0; b < 2; ++b) { dev_free(&c->keys[b]); dev_free(&c->vals[b]); }
     for (int b = 0; b < GSX_PERM_RING; ++b) dev_free(&c->perm[b]);
     dev_free(&c->sort_ws); dev_free(&c->aabb_dev); dev_free(&c->flags);
@@ -232,7 +237,7 @@ int gsx_set_option(gsx_ctx* c, const char* name, uint64_t value) {
     } else if (!std::strcmp(name, "no_history")) {
         c->opt_no_history = value ? 1 : 0;
     } else if (!std::strcmp(name, "lod_walk")) {
-        c->opt_lod_walk = value ? 1 : 0;
+        c->opt_lod_walk = value > 2 ? 1 : value;      // 0: head + tail + one-launch compaction; 1: ancestor walk; 2: a launch per level (both with the three-launch compaction)
     } else if (!std::strcmp(name, "tile_caps")) {
         c->opt_tile_caps = value > 2 ? 1 : value;      // (2: caps at 1/8 of the predicted depth - exercises the redo path in tests)
     } else if (!std::strcmp(name, "tile_caps_radius")) {
@@ -496,6 +501,8 @@ int gsx_set_lod_octree(gsx_ctx* c, const gsx_octree_flat* t) {
                 if ((w & 15u) == 0u) w = i << 4;
                 if ((w & 15u) == 15u || (w >> 4) + (w & 15u) != i) bfs = false; else ++w;
             }
+            c->lod_max_children = 0;
+            for (uint32_t i = 0; i < n; ++i) c->lod_max_children = std::max(c->lod_max_children, cw[i] & 15u);
         } else {
             bfs = false;
         }

@@ -100,7 +100,8 @@ struct GsxDevFlags {
     uint32_t wide_m;         // key count of the gated top-digit pass of the depth sort: 0, or m once a key needed the top bits
     uint32_t bad_index;      // a selection list named an id >= n
     uint32_t key_bound;      // a depth key fell outside the host-computed [dmin, dmax] bound (NaN position?)
-    uint32_t pad[3];
+    uint32_t lod_fault;      // 1: the one-launch compaction timed out waiting for a workgroup's count; 2: the octree walk's LDS stack overflowed
+    uint32_t pad[2];
 };
 
 // Screen-space record of a projected splat: quad corner q in [-1,1]^2 sits at c + q.x*A + q.y*B (pixels);
@@ -224,6 +225,9 @@ struct gsx_ctx : GsxFrameSlot {
     uint32_t lod_stamp = 255;                           // frame stamp in the emit bytes (255 = clear them first)
     uint32_t* lod_queue[2] = {nullptr, nullptr};        // per-level worklists (ping-pong), lod_nodes ids each
     uint32_t* lod_qcount = nullptr;                     // queue length per level (zeroed by the compaction's scan kernel after every cut)
+    uint32_t lod_max_children = 0;                      // of any node (the in-LDS walk is sized for <= 8)
+    uint64_t* lod_agg = nullptr;                        // one-launch compaction: (cut number << 32 | count) per workgroup
+    uint32_t lod_seq = 0;                               // cut number of the last compaction
     uint32_t* lod_top_anc = nullptr;                    // 8 ids per top node: itself and its ancestors (UINT32_MAX = none)
 
     // sort

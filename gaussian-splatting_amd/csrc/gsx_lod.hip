@@ -154,6 +154,110 @@ __global__ __launch_bounds__(NT) void k_octree_level(const float4* __restrict__ 
     for (uint32_t k = 0; k < nc; ++k) queue_out[base + k] = fc + k;
 }
 
+// ---- the same walk in two launches (round 3) -------------------------------------------------------------------
+// One launch per level costs four dependent trips to memory (queue length, queue entry, node, slot reservation) plus the
+// launch itself: ~9.5 us a level whatever its width.  Inside a workgroup a level costs one trip (the node) and a block scan.
+//  k_octree_head: the leading levels as in k_octree_top, eight top nodes per workgroup, then up to two more levels from
+//                 queues in LDS (<= 64 and <= 512 nodes: every child of every node fits); the frontier below them goes to the
+//                 global queue, which deals it out evenly again - that is where the subtrees' sizes start to differ.
+//  k_octree_tail: a workgroup takes 256 entries of that queue and walks everything below them from a stack in LDS, deepest
+//                 nodes first.  The stack is ordered by level (children are pushed above everything that stays), a level's
+//                 entries are only pushed when all deeper ones fit the same pop, so a level never holds more than 8 x 256
+//                 entries: capacity = 8 x 256 x (levels below the queue's), no spill path needed.  The entries are dealt
+//                 out in groups of 8 (a cache line of boxes), round-robin over the workgroups: where the cut runs deep,
+//                 EVERY node of a region expands eightfold, and a workgroup holding 256 neighbours walked 9 rounds one
+//                 after another while 60 % of the others were done after one (58 us at cfg 3); dealt out, every
+//                 workgroup walks 2 to 4 rounds (tools/_dbg/lod_tail_sim.py).
+#define GSX_HEAD_NT 512
+#define GSX_HEAD_G 8u            // top nodes per workgroup: x 8 slots = wave 0
+__global__ __launch_bounds__(GSX_HEAD_NT) void k_octree_head(const float4* __restrict__ a, const float4* __restrict__ b,
+                                                             const uint8_t* __restrict__ leaf, const uint32_t* __restrict__ child,
+                                                             const uint32_t* __restrict__ top_anc, uint32_t top_end, uint32_t last_begin,
+                                                             uint32_t walk, uint32_t out_level, GsxMat4 vp, float thr, uint8_t stamp,
+                                                             uint8_t* __restrict__ emit, uint32_t* __restrict__ queue_out,
+                                                             uint32_t* __restrict__ qcount) {
+    __shared__ uint32_t s_tmp[GSX_HEAD_NT / 64];
+    __shared__ uint32_t s_base;
+    __shared__ uint32_t s_q[2][GSX_HEAD_NT];
+    const uint32_t tid = threadIdx.x;
+    uint32_t fc = 0, nc = 0;
+    if (tid < 64u) {                                    // wave 0: a top node and its ancestors in eight adjacent lanes
+        const uint32_t gid = blockIdx.x * 64u + tid, node = gid >> 3, slot = gid & 7u;
+        const uint32_t id = node < top_end ? top_anc[gid] : 0xFFFFFFFFu;
+        const bool stops = id != 0xFFFFFFFFu && gsx_octree_node_stops(a, b, leaf, id, vp, thr);
+        const uint32_t group = static_cast<uint32_t>(__builtin_amdgcn_ballot_w64(stops) >> (tid & ~7u)) & 0xFFu;
+        if (slot == 0u && node < top_end && (group & 0xFEu) == 0u) {   // reached: no ancestor stops
+            if (group & 1u) emit[node] = stamp;
+            else if (node >= last_begin) { const uint32_t cw = child[node]; fc = cw >> 4; nc = cw & 15u; }
+        }
+    }
+    for (uint32_t r = 0; r < walk; ++r) {               // levels walked from LDS: <= 8 children per node (checked at set-up), so 64, then 512 entries
+        uint32_t total;
+        const uint32_t excl = gsx_block_excl_scan<GSX_HEAD_NT>(nc, s_tmp, &total);
+        if (total == 0u) return;                        // (uniform)
+        uint32_t* q = s_q[r & 1u];
+        for (uint32_t k = 0; k < nc; ++k) q[excl + k] = fc + k;
+        __syncthreads();
+        fc = nc = 0;
+        if (tid < total) {
+            const uint32_t i = q[tid];
+            const uint32_t cw = child[i];
+            if (gsx_octree_node_stops(a, b, leaf, i, vp, thr)) emit[i] = stamp;
+            else { fc = cw >> 4; nc = cw & 15u; }
+        }
+    }
+    uint32_t total;                                     // the frontier: to the global queue
+    const uint32_t excl = gsx_block_excl_scan<GSX_HEAD_NT>(nc, s_tmp, &total);
+    if (total == 0u) return;                            // (uniform)
+    if (tid == 0) s_base = atomicAdd(&qcount[out_level], total);
+    __syncthreads();
+    const uint32_t base = s_base + excl;
+    for (uint32_t k = 0; k < nc; ++k) queue_out[base + k] = fc + k;
+}
+
+#define GSX_TAIL_NT 256
+#define GSX_TAIL_MAX_DEPTH 6u    // levels below the queue's: 8 x 256 x 6 entries = 48 KB of LDS
+__global__ __launch_bounds__(GSX_TAIL_NT) void k_octree_tail(const float4* __restrict__ a, const float4* __restrict__ b,
+                                                             const uint8_t* __restrict__ leaf, const uint32_t* __restrict__ child,
+                                                             uint32_t n, uint32_t level, uint32_t cap, GsxMat4 vp, float thr, uint8_t stamp,
+                                                             uint8_t* __restrict__ emit, const uint32_t* __restrict__ queue_in,
+                                                             const uint32_t* __restrict__ qcount, GsxDevFlags* __restrict__ flags) {
+    extern __shared__ uint32_t s_stack[];
+    __shared__ uint32_t s_tmp[GSX_TAIL_NT / 64];
+    const uint32_t cnt = qcount[level] < n ? qcount[level] : n, tid = threadIdx.x;
+    const uint32_t wgs = (cnt + GSX_TAIL_NT - 1u) / GSX_TAIL_NT;                 // workgroups that have work
+    if (blockIdx.x >= wgs) return;                      // the whole workgroup is past the queue
+    uint32_t sp = 0;                                    // entries on the stack (uniform)
+    const uint32_t first = ((tid >> 3) * wgs + blockIdx.x) * 8u + (tid & 7u);   // groups of 8 entries, dealt round-robin
+    uint32_t i = first < cnt ? queue_in[first] : 0xFFFFFFFFu;
+    for (;;) {
+        uint32_t fc = 0, nc = 0;
+        if (i != 0xFFFFFFFFu && i >= n) {               // (a queue entry that is no node: never follow it)
+            atomicOr(&flags->lod_fault, 4u);
+            i = 0xFFFFFFFFu;
+        }
+        if (i != 0xFFFFFFFFu) {
+            const uint32_t cw = child[i];
+            if (gsx_octree_node_stops(a, b, leaf, i, vp, thr)) emit[i] = stamp;
+            else { fc = cw >> 4; nc = cw & 15u; }
+        }
+        uint32_t total;
+        const uint32_t pos = sp + gsx_block_excl_scan<GSX_TAIL_NT>(nc, s_tmp, &total);
+        for (uint32_t k = 0; k < nc; ++k)
+            if (pos + k < cap) s_stack[pos + k] = fc + k;
+        sp += total;
+        if (sp > cap) {                                 // (cannot happen, see above; never write past the stack)
+            if (tid == 0) atomicOr(&flags->lod_fault, 2u);
+            sp = cap;
+        }
+        if (sp == 0u) return;                           // (uniform)
+        __syncthreads();
+        const uint32_t np = sp < GSX_TAIL_NT ? sp : GSX_TAIL_NT;
+        sp -= np;
+        i = tid < np ? s_stack[sp + tid] : 0xFFFFFFFFu; // (the scan's barriers stand between this read and the next push)
+    }
+}
+
 // emit[i] = stop[i] && no ancestor stops.  Chains are as deep as the tree; most
 // walks end after a step or two because an ancestor near the cut stops.
 __global__ __launch_bounds__(256) void k_emit_flags(const uint8_t* __restrict__ stop, const uint32_t* __restrict__ parent,
@@ -240,8 +344,99 @@ __global__ __launch_bounds__(GSX_CMP_NT) void k_compact_write(const uint8_t* __r
     }
 }
 
+// The same compaction in ONE launch (round 3): at most 512 workgroups, all resident at once (512 threads and 33 KB of LDS
+// each: half the chip's wave slots), every one owning a contiguous span of the flags.  A workgroup counts its span, publishes
+// the count as (cut number << 32 | count) with a device-scope store, sums the counts of the workgroups before it as they
+// appear, then reads its span again (from L2) and writes the ids, staged through LDS so that the stores are whole lines.
+// No chain: a workgroup waits for counts only, and every workgroup publishes its count before it waits for anything.  The
+// wait is bounded (a workgroup that never appears would otherwise hang the grid): on time-out the cut is flagged as failed.
+#define GSX_CP1_NT 512
+#define GSX_CP1_MAXG 512u
+#define GSX_CP1_SPIN_LIMIT (1u << 20)
+__device__ __forceinline__ uint32_t gsx_count_unit(const uint8_t* flags, uint32_t u, uint32_t n, uint32_t match, uint32_t w[4]) {
+    const uint4 v = *reinterpret_cast<const uint4*>(flags + static_cast<uint64_t>(u) * 16u);
+    w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+    uint32_t cnt = 0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const bool on = ((w[j >> 2] >> (8 * (j & 3))) & 0xFFu) == match && (u * 16u + j) < n;
+        cnt += on ? 1u : 0u;
+    }
+    return cnt;
+}
+
+__global__ __launch_bounds__(GSX_CP1_NT) void k_compact_onepass(const uint8_t* __restrict__ flags, uint32_t n, uint32_t match,
+                                                                uint32_t units_per_wg, uint64_t* __restrict__ agg, uint32_t seq,
+                                                                uint32_t* __restrict__ out, uint32_t* __restrict__ m_out,
+                                                                uint32_t* __restrict__ qcount, GsxDevFlags* __restrict__ dflags) {
+    __shared__ uint32_t s_tmp[GSX_CP1_NT / 64];
+    __shared__ uint32_t s_prefix;
+    __shared__ uint32_t s_ids[GSX_CP1_NT * 16];
+    const uint32_t tid = threadIdx.x, units = (n + 15u) / 16u;
+    const uint32_t u0 = blockIdx.x * units_per_wg, u1 = u0 + units_per_wg < units ? u0 + units_per_wg : units;
+    if (blockIdx.x == 0 && qcount && tid <= GSX_LOD_MAX_LEVELS + 1) qcount[tid] = 0u;   // the octree cut's level counters, for the next cut
+    uint32_t w[4], cnt = 0;
+    for (uint32_t u = u0 + tid; u < u1; u += GSX_CP1_NT) cnt += gsx_count_unit(flags, u, n, match, w);
+    uint32_t total;
+    gsx_block_excl_scan<GSX_CP1_NT>(cnt, s_tmp, &total);
+    if (tid == 0) __hip_atomic_store(&agg[blockIdx.x], (static_cast<uint64_t>(seq) << 32) | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid < 64u) {
+        uint32_t sum = 0;
+        bool late = false;
+        for (uint32_t p = tid; p < blockIdx.x; p += 64u) {
+            uint64_t v = __hip_atomic_load(&agg[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (uint32_t spins = 0; static_cast<uint32_t>(v >> 32) != seq && spins < GSX_CP1_SPIN_LIMIT; ++spins) {
+                __builtin_amdgcn_s_sleep(2);
+                v = __hip_atomic_load(&agg[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (static_cast<uint32_t>(v >> 32) != seq) late = true;
+            else sum += static_cast<uint32_t>(v);
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+        if (late) atomicOr(&dflags->lod_fault, 1u);
+        if (tid == 0) s_prefix = sum;
+    }
+    __syncthreads();
+    uint32_t run = s_prefix;
+    if (blockIdx.x == gridDim.x - 1 && tid == 0) *m_out = run + total;
+    for (uint32_t ub = u0; ub < u1; ub += GSX_CP1_NT) {             // (uniform)
+        const uint32_t u = ub + tid;
+        w[0] = w[1] = w[2] = w[3] = 0u;
+        const uint32_t c = u < u1 ? gsx_count_unit(flags, u, n, match, w) : 0u;
+        uint32_t tile_total;
+        uint32_t pos = gsx_block_excl_scan<GSX_CP1_NT>(c, s_tmp, &tile_total);
+        if (c) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const bool on = ((w[j >> 2] >> (8 * (j & 3))) & 0xFFu) == match && (u * 16u + j) < n;
+                if (on) s_ids[pos++] = u * 16u + j;
+            }
+        }
+        __syncthreads();
+        for (uint32_t k = tid; k < tile_total; k += GSX_CP1_NT) out[run + k] = s_ids[k];
+        run += tile_total;
+        __syncthreads();
+    }
+}
+
 // ids whose flag byte equals `match`, ascending
 static int compact(gsx_ctx* c, uint32_t n, uint32_t match = 1u) {
+    if (!c->opt_lod_walk) {
+        const uint32_t units = gsx_div_up(n, 16u);
+        uint32_t g = gsx_div_up(units, static_cast<uint32_t>(GSX_CP1_NT));
+        g = g < 1u ? 1u : (g > GSX_CP1_MAXG ? GSX_CP1_MAXG : g);
+        const uint32_t per = gsx_div_up(gsx_div_up(units, g), static_cast<uint32_t>(GSX_CP1_NT)) * GSX_CP1_NT;   // whole tiles
+        g = per ? gsx_div_up(units, per) : 1u;
+        if (++c->lod_seq == 0u) {                       // cut numbers wrapped: forget the old counts
+            GSX_HIP(c, hipMemsetAsync(c->lod_agg, 0, GSX_CP1_MAXG * sizeof(uint64_t), c->sel_stream));
+            c->lod_seq = 1u;
+        }
+        hipLaunchKernelGGL(k_compact_onepass, dim3(g), dim3(GSX_CP1_NT), 0, c->sel_stream, c->lod_emit, n, match, per, c->lod_agg,
+                           c->lod_seq, c->sel_idx, c->m_dev, c->lod_qcount, c->flags);
+        GSX_HIP(c, hipGetLastError());
+        return GSX_OK;
+    }
     const uint32_t nb = gsx_div_up(n, GSX_CMP_TILE);
     hipLaunchKernelGGL(k_compact_count, dim3(nb), dim3(GSX_CMP_NT), 0, c->sel_stream, c->lod_emit, n, match, c->lod_block_sums);
     hipLaunchKernelGGL(k_scan_block_sums, dim3(1), dim3(1024), 0, c->sel_stream, c->lod_block_sums, nb, c->m_dev, c->lod_qcount);
@@ -257,7 +452,7 @@ int gsx_launch_select_octree(gsx_ctx* c, const float vp[16], float thr) {
     for (int i = 0; i < 16; ++i) m.m[i] = vp[i];
     if (c->profiling) GSX_HIP(c, hipEventRecord(c->ev[EV_SEL0], c->sel_stream));
     uint32_t match = 1u;
-    if (c->lod_levels && !c->opt_lod_walk) {
+    if (c->lod_levels && c->opt_lod_walk != 1) {
         GsxLodLevels lv;
         for (uint32_t l = 0; l <= GSX_LOD_MAX_LEVELS; ++l) lv.start[l] = l <= c->lod_levels ? c->lod_level_start[l] : n;
         if (c->lod_stamp >= 255u) {     // stamps are used up (or another path wrote flags into the bytes): start over
@@ -266,12 +461,29 @@ int gsx_launch_select_octree(gsx_ctx* c, const float vp[16], float thr) {
         }
         match = ++c->lod_stamp;
         const uint32_t top = c->lod_top_levels;
-        hipLaunchKernelGGL(k_octree_top, dim3(gsx_div_up(lv.start[top] * 8u, GSX_TOP_NT)), dim3(GSX_TOP_NT), 0, c->sel_stream, c->lod_a, c->lod_b,
-                           c->lod_leaf, c->lod_child, c->lod_top_anc, lv.start[top], lv.start[top - 1u], top, m, thr,
-                           static_cast<uint8_t>(match), c->lod_emit, c->lod_queue[top & 1u], c->lod_qcount);
-        for (uint32_t l = top; l < c->lod_levels; ++l) {
+        uint32_t l = top;                               // first level that is walked from the global queue
+        if (c->opt_lod_walk == 0 && c->lod_max_children <= 8u) {
+            const uint32_t walk = c->lod_levels - top < 2u ? c->lod_levels - top : 2u;
+            l = top + walk;
+            hipLaunchKernelGGL(k_octree_head, dim3(gsx_div_up(lv.start[top], GSX_HEAD_G)), dim3(GSX_HEAD_NT), 0, c->sel_stream, c->lod_a,
+                               c->lod_b, c->lod_leaf, c->lod_child, c->lod_top_anc, lv.start[top], lv.start[top - 1u], walk, l, m, thr,
+                               static_cast<uint8_t>(match), c->lod_emit, c->lod_queue[l & 1u], c->lod_qcount);
+        } else {
+            hipLaunchKernelGGL(k_octree_top, dim3(gsx_div_up(lv.start[top] * 8u, GSX_TOP_NT)), dim3(GSX_TOP_NT), 0, c->sel_stream, c->lod_a, c->lod_b,
+                               c->lod_leaf, c->lod_child, c->lod_top_anc, lv.start[top], lv.start[top - 1u], top, m, thr,
+                               static_cast<uint8_t>(match), c->lod_emit, c->lod_queue[top & 1u], c->lod_qcount);
+        }
+        for (; l < c->lod_levels; ++l) {
             // (the queue's length is only known on the device: the grid covers the level, workgroups past the queue leave at once)
             const uint32_t width = lv.start[l + 1] - lv.start[l];
+            const uint32_t below = c->lod_levels - 1u - l;
+            if (c->opt_lod_walk == 0 && c->lod_max_children <= 8u && below <= GSX_TAIL_MAX_DEPTH) {   // everything from here down in one launch
+                const uint32_t cap = 8u * GSX_TAIL_NT * (below ? below : 1u);
+                hipLaunchKernelGGL(k_octree_tail, dim3(gsx_div_up(width, GSX_TAIL_NT)), dim3(GSX_TAIL_NT), cap * sizeof(uint32_t), c->sel_stream,
+                                   c->lod_a, c->lod_b, c->lod_leaf, c->lod_child, n, l, cap, m, thr, static_cast<uint8_t>(match), c->lod_emit,
+                                   c->lod_queue[l & 1u], c->lod_qcount, c->flags);
+                break;
+            }
             if (width <= (256u << 10))
                 hipLaunchKernelGGL(k_octree_level<256>, dim3(gsx_div_up(width, 256)), dim3(256), 0, c->sel_stream, c->lod_a, c->lod_b,
                                    c->lod_leaf, c->lod_child, l, m, thr, static_cast<uint8_t>(match), c->lod_emit, c->lod_queue[l & 1u],

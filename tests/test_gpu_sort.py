@@ -507,7 +507,9 @@ def test_cfg3_octree_orbit_at_6m(gsx_fresh, pkg, oracle, synth):
         gsx.set_option("lod_walk", 1)
         m_walk = gsx.select_octree(vp, 0.002)
         walk = gsx.selection()
-        gsx.set_option("lod_walk", 0)
+        gsx.set_option("lod_walk", 2)                    # a launch per level, three-launch compaction (round 2's form)
+        assert gsx.select_octree(vp, 0.002) == m_walk and np.array_equal(gsx.selection(), walk)
+        gsx.set_option("lod_walk", 0)                    # head + tail + one-launch compaction
         m = gsx.select_octree(vp, 0.002)
         cut = gsx.selection()
         assert m == m_walk and np.array_equal(cut, walk)

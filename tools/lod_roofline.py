@@ -35,17 +35,18 @@ with pkg.Gsx(0) as g:
             cur = np.unique(tree.parent[cur])
             cur = cur[cur != 0xFFFFFFFF]
         looked.append(int(seen.sum())); emitted.append(int(m))
-cuts = next(c for n, (c, a) in stats.items() if n.startswith("k_octree_top"))
-walk_us = total_us("k_octree_top", cuts) + total_us("k_octree_level", cuts)
-comp_us = total_us("k_compact_count", cuts) + total_us("k_scan_block_sums", cuts) + total_us("k_compact_write", cuts)
+cuts = next(c for n, (c, a) in stats.items() if n.startswith("k_compact_onepass") or n.startswith("k_compact_write"))
+walk_us = sum(total_us(k, cuts) for k in ("k_octree_top", "k_octree_level", "k_octree_head", "k_octree_tail"))
+comp_us = sum(total_us(k, cuts) for k in ("k_compact_count", "k_scan_block_sums", "k_compact_write", "k_compact_onepass"))
+names = sorted(n.split("(")[0] for n in stats if any(n.startswith(k) or (" " + k) in n for k in ("k_octree", "k_compact", "k_scan_block")))
 L, E, N = float(np.mean(looked)), float(np.mean(emitted)), int(tree.n)
 walk_bytes = L * (4 + 33 + 4) + (L - 1) * 4 + E
 comp_bytes = 2 * N + 4 * E
 print(json.dumps({"tree_nodes": N, "nodes_looked_at": looked, "nodes_emitted": emitted,
-                  "walk": {"kernels": "k_octree_top + k_octree_level x levels", "us_per_cut": walk_us, "bytes_per_cut": walk_bytes,
+                  "launches": names, "walk": {"kernels": "k_octree_head + k_octree_tail (or k_octree_top + k_octree_level x levels)", "us_per_cut": walk_us, "bytes_per_cut": walk_bytes,
                            "hbm_gbs": walk_bytes / (walk_us * 1e-6) / 1e9, "hbm_frac": walk_bytes / (walk_us * 1e-6) / 1e9 / 8000.0,
                            "bound": "launch + latency (one dependent launch per level) and VALU (~430 instructions per stop test), not HBM"},
-                  "compaction": {"kernels": "k_compact_count + k_scan_block_sums + k_compact_write", "us_per_cut": comp_us, "bytes_per_cut": comp_bytes,
+                  "compaction": {"kernels": "k_compact_onepass (or k_compact_count + k_scan_block_sums + k_compact_write)", "us_per_cut": comp_us, "bytes_per_cut": comp_bytes,
                                  "hbm_gbs": comp_bytes / (comp_us * 1e-6) / 1e9, "hbm_frac": comp_bytes / (comp_us * 1e-6) / 1e9 / 8000.0,
                                  "bound": "launch latency (three dependent launches over 8.5 MB of flags)"},
                   "all_nodes_tested_instead": {"bytes": N * 34.0, "note": "what round 1's k_octree_stop read per cut"}}, indent=1))
