@@ -123,6 +123,7 @@ int gsx_create(int device, gsx_ctx** out) {
     {
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus < 1) cus = 256;
+        c->cus = static_cast<uint32_t>(cus);
         c->sort_slots = gsx_sort_slots(cus);
         c->pair_slots = gsx_pair_slots(cus);
     }
@@ -173,7 +174,7 @@ int gsx_destroy(gsx_ctx* c) {
     if (c->active_slot) gsx_slot_switch(c);          // slot 0 (the main stream's) back into the base
     dev_free(&c->pos4); dev_free(&c->pos3); dev_free(&c->geo);
     dev_free(&c->sel_idx); dev_free(&c->m_dev); dev_free(&c->m_perm);
-    dev_free(&c->lod_a); dev_free(&c->lod_b); dev_free(&c->lod_parent); dev_free(&c->lod_leaf); dev_free(&c->lod_child); dev_free(&c->lod_queue[0]); dev_free(&c->lod_queue[1]); dev_free(&c->lod_qcount); dev_free(&c->lod_top_anc);
+    dev_free(&c->lod_a); dev_free(&c->lod_b); dev_free(&c->lod_parent); dev_free(&c->lod_leaf); dev_free(&c->lod_child); dev_free(&c->lod_queue[0]); dev_free(&c->lod_queue[1]); dev_free(&c->lod_qcount); dev_free(&c->lod_top_anc); dev_free(&c->lod_head_ranges); dev_free(&c->lod_node);
     dev_free(&c->lod_stop); dev_free(&c->lod_emit); dev_free(&c->lod_block_sums); dev_free(&c->lod_agg);
     for (int b = 0; b < 2; ++b) { dev_free(&c->keys[b]); dev_free(&c->vals[b]); }
     for (int b = 0; b < GSX_PERM_RING; ++b) dev_free(&c->perm[b]);
@@ -524,6 +525,37 @@ int gsx_set_lod_octree(gsx_ctx* c, const gsx_octree_flat* t) {
             }
             if ((rc = dev_alloc(c, &c->lod_top_anc, static_cast<uint64_t>(top_end) * 8u))) return rc;
             GSX_HIP(c, hipMemcpy(c->lod_top_anc, anc.data(), anc.size() * 4, hipMemcpyHostToDevice));
+            {   // the walk kernels' 32-byte node records
+                std::vector<uint32_t> rec(static_cast<size_t>(n) * 8u);
+                for (uint32_t i = 0; i < n; ++i) {
+                    std::memcpy(&rec[8u * i], &a[4u * i], 16);
+                    std::memcpy(&rec[8u * i + 4u], &b[4u * i], 8);
+                    rec[8u * i + 6u] = cw[i];
+                    rec[8u * i + 7u] = t->is_leaf[i] ? 1u : 0u;
+                }
+                if ((rc = dev_alloc(c, &c->lod_node, static_cast<uint64_t>(n) * 2u))) return rc;
+                GSX_HIP(c, hipMemcpy(c->lod_node, rec.data(), rec.size() * 4, hipMemcpyHostToDevice));
+            }
+            c->lod_deepest_leaf = true;
+            for (uint32_t i = c->lod_level_start[levels - 1u]; i < n; ++i) c->lod_deepest_leaf = c->lod_deepest_leaf && t->is_leaf[i] != 0;
+            // k_octree_head: the descendants one and two levels below each group of 8 top nodes (contiguous ranges in BFS order)
+            const uint32_t walk = levels - c->lod_top_levels < 2u ? levels - c->lod_top_levels : 2u;
+            const uint32_t last_begin = c->lod_level_start[c->lod_top_levels - 1u], groups = (top_end + 7u) / 8u;
+            std::vector<uint32_t> rg(static_cast<size_t>(groups) * 4u, 0u);
+            auto children_of = [&](uint32_t lo, uint32_t hi, uint32_t* first, uint32_t* count) {
+                uint32_t b = 0, e = 0;
+                for (uint32_t i = lo; i < hi; ++i)
+                    if (cw[i] & 15u) { if (e == b) b = cw[i] >> 4; e = (cw[i] >> 4) + (cw[i] & 15u); }
+                *first = b; *count = e - b;
+            };
+            for (uint32_t g = 0; g < groups; ++g) {
+                const uint32_t lo = std::max(g * 8u, last_begin), hi = std::min(g * 8u + 8u, top_end);
+                if (walk >= 1u && lo < hi) children_of(lo, hi, &rg[g * 4u], &rg[g * 4u + 1u]);
+                if (walk >= 2u && rg[g * 4u + 1u]) children_of(rg[g * 4u], rg[g * 4u] + rg[g * 4u + 1u], &rg[g * 4u + 2u], &rg[g * 4u + 3u]);
+                if (rg[g * 4u + 1u] > 64u || rg[g * 4u + 3u] > 512u) c->lod_max_children = 99u;   // (cannot happen with <= 8 children: the head kernel is not used then)
+            }
+            if ((rc = dev_alloc(c, &c->lod_head_ranges, groups))) return rc;
+            GSX_HIP(c, hipMemcpy(c->lod_head_ranges, rg.data(), rg.size() * 4, hipMemcpyHostToDevice));
         }
     }
     c->lod_stamp = 255;

@@ -225,6 +225,9 @@ struct gsx_ctx : GsxFrameSlot {
     uint32_t lod_stamp = 255;                           // frame stamp in the emit bytes (255 = clear them first)
     uint32_t* lod_queue[2] = {nullptr, nullptr};        // per-level worklists (ping-pong), lod_nodes ids each
     uint32_t* lod_qcount = nullptr;                     // queue length per level (zeroed by the compaction's scan kernel after every cut)
+    uint4* lod_node = nullptr;                          // 2 x 16 bytes per node: (cx, cy, cz, hx), (hy, hz, child word, leaf)
+    uint4* lod_head_ranges = nullptr;                   // per group of 8 top nodes: (first, count) of their descendants one and two levels down
+    bool lod_deepest_leaf = false;                      // every node of the deepest level has is_leaf set
     uint32_t lod_max_children = 0;                      // of any node (the in-LDS walk is sized for <= 8)
     uint64_t* lod_agg = nullptr;                        // one-launch compaction: (cut number << 32 | count) per workgroup
     uint32_t lod_seq = 0;                               // cut number of the last compaction
@@ -261,6 +264,7 @@ struct gsx_ctx : GsxFrameSlot {
     uint32_t sort_launches = 0;
     uint32_t sort_passes = 0;
     bool sort_gated = false;   // the latest depth sort queued a gated top-digit pass (counted in sort_passes)
+    uint32_t cus = 256;                              // compute units of the device
     uint32_t sort_slots = 1024, pair_slots = 1024;   // resident workgroups of the scatter kernels (CUs x blocks/CU)
     float cam[3] = {0, 0, 0};
     float aabb_min[3] = {0, 0, 0}, aabb_max[3] = {0, 0, 0};  // of the uploaded positions

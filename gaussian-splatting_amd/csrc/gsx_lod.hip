@@ -84,11 +84,78 @@ __global__ __launch_bounds__(256) void k_hc_stop(const float4* __restrict__ ew, 
 // handled by ONE workgroup: it evaluates all of them at once (no dependence between levels there) and then resolves
 // reachability in LDS, so a frame pays one launch and one memory round trip for them instead of five.
 // emit bytes carry a frame stamp (1..255) and compaction matches it, so the array is cleared every 255 cuts, not per cut.
+// `screen_area < thr` decided from a cheap evaluation with an error bound; false = too close to call (or not finite, or a
+// corner near the camera plane): the caller then evaluates gsx_screen_area, so the decision is ALWAYS the exactly rounded
+// one.  The exact evaluation is ~430 instructions (8 corners x 3 matrix rows in glm's order, 16 IEEE divisions); this one
+// ~150: a corner's clip coordinates are base +- ax +- ay +- az per row (fused multiply-adds, shared partial sums), one
+// v_rcp_f32 per corner.  Bound: both evaluations of a row are within 6 roundings x 2^-24 x S of the real value, S = the
+// sum of the row's absolute terms, so they differ by < 2^-20 S; the quotients then differ by (d0 + |n| d3) / min|w| plus
+// 4 ulp for the reciprocal and the product; the area by the usual product rule.  The whole margin is doubled again.
+// The exact code clamps at +-1e7 (its min/max start values): coordinates beyond 1e6 go to the exact evaluation.
+__device__ __forceinline__ bool gsx_area_below_fast(float cx, float cy, float cz, float hx, float hy, float hz, const GsxMat4& vp,
+                                                    float thr, bool* below) {
+    float x[8], y[8], w[8], d[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int r = k == 2 ? 3 : k;                   // rows 0, 1, 3 (z is not used)
+        const float m0 = vp.m[r], m1 = vp.m[4 + r], m2 = vp.m[8 + r], m3 = vp.m[12 + r];
+        const float base = __builtin_fmaf(m0, cx, __builtin_fmaf(m1, cy, __builtin_fmaf(m2, cz, m3)));
+        const float ax = m0 * hx, ay = m1 * hy, az = m2 * hz;
+        const float sum = __builtin_fmaf(fabsf(m0), fabsf(cx), __builtin_fmaf(fabsf(m1), fabsf(cy), __builtin_fmaf(fabsf(m2), fabsf(cz), fabsf(m3)))) +
+                          (fabsf(ax) + fabsf(ay) + fabsf(az));
+        d[k] = sum * 9.5367431640625e-07f;              // 2^-20 S
+        float* out = k == 0 ? x : (k == 1 ? y : w);
+        const float b0 = base - ax, b1 = base + ax;
+        const float c0 = b0 - ay, c1 = b0 + ay, c2 = b1 - ay, c3 = b1 + ay;
+        out[0] = c0 - az; out[1] = c0 + az; out[2] = c1 - az; out[3] = c1 + az;
+        out[4] = c2 - az; out[5] = c2 + az; out[6] = c3 - az; out[7] = c3 + az;
+    }
+    float mnx, mxx, mny, mxy, wmin;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const float rw = __builtin_amdgcn_rcpf(w[i]);
+        const float nx = x[i] * rw, ny = y[i] * rw, aw = fabsf(w[i]);
+        if (i == 0) { mnx = mxx = nx; mny = mxy = ny; wmin = aw; }
+        else { mnx = fminf(mnx, nx); mxx = fmaxf(mxx, nx); mny = fminf(mny, ny); mxy = fmaxf(mxy, ny); wmin = fminf(wmin, aw); }
+    }
+    const float wlo = wmin - d[2];
+    const float nxm = fmaxf(fabsf(mnx), fabsf(mxx)), nym = fmaxf(fabsf(mny), fabsf(mxy));
+    const float iw = __builtin_amdgcn_rcpf(wlo) * 1.0001f;
+    const float ex = __builtin_fmaf(nxm, d[2], d[0]) * iw + nxm * 4.76837158203125e-07f;   // + 2^-21 |n|
+    const float ey = __builtin_fmaf(nym, d[2], d[1]) * iw + nym * 4.76837158203125e-07f;
+    const float dx = mxx - mnx, dy = mxy - mny, area = dx * dy;
+    const float margin = 4.0f * (ex * (dy + ey) + ey * (dx + ex)) + area * 4.76837158203125e-07f;
+    // (every comparison is false for a NaN: not decided)
+    if (!(wlo > 1.0e-30f) || !(nxm < 1.0e6f) || !(nym < 1.0e6f) || !(fabsf(area - thr) > margin)) return false;
+    *below = area < thr;
+    return true;
+}
+
+// One 32-byte record per node for the walk kernels (a node costs one line request instead of four: box centre + half x,
+// half y / z, child word, leaf flag); k_octree_stop and the per-level kernels keep the separate arrays.
+struct GsxOctNode { float cx, cy, cz, hx, hy, hz; uint32_t child, leaf; };
+static_assert(sizeof(GsxOctNode) == 32, "two 16-byte loads");
+__device__ __forceinline__ GsxOctNode gsx_load_node(const GsxOctNode* __restrict__ nodes, uint32_t i) {
+    const uint4 lo = reinterpret_cast<const uint4*>(nodes)[2u * i], hi = reinterpret_cast<const uint4*>(nodes)[2u * i + 1u];
+    GsxOctNode nd;
+    nd.cx = __uint_as_float(lo.x); nd.cy = __uint_as_float(lo.y); nd.cz = __uint_as_float(lo.z); nd.hx = __uint_as_float(lo.w);
+    nd.hy = __uint_as_float(hi.x); nd.hz = __uint_as_float(hi.y); nd.child = hi.z; nd.leaf = hi.w;
+    return nd;
+}
+__device__ __forceinline__ bool gsx_node_stops(const GsxOctNode& nd, const GsxMat4& vp, float thr) {
+    bool below;
+    if (!gsx_area_below_fast(nd.cx, nd.cy, nd.cz, nd.hx, nd.hy, nd.hz, vp, thr, &below))
+        below = gsx_screen_area(nd.cx, nd.cy, nd.cz, nd.hx, nd.hy, nd.hz, vp) < thr;
+    return nd.leaf != 0u || below;    // Octree.cpp:203
+}
+
 __device__ __forceinline__ bool gsx_octree_node_stops(const float4* __restrict__ a, const float4* __restrict__ b,
                                                       const uint8_t* __restrict__ leaf, uint32_t i, const GsxMat4& vp, float thr) {
     const float4 ca = a[i], cb = b[i];
-    const float area = gsx_screen_area(ca.x, ca.y, ca.z, ca.w, cb.x, cb.y, vp);
-    return leaf[i] || (area < thr);   // Octree.cpp:203
+    bool below;
+    if (!gsx_area_below_fast(ca.x, ca.y, ca.z, ca.w, cb.x, cb.y, vp, thr, &below))
+        below = gsx_screen_area(ca.x, ca.y, ca.z, ca.w, cb.x, cb.y, vp) < thr;
+    return leaf[i] || below;          // Octree.cpp:203
 }
 
 struct GsxLodLevels { uint32_t start[GSX_LOD_MAX_LEVELS + 1]; };
@@ -157,56 +224,75 @@ __global__ __launch_bounds__(NT) void k_octree_level(const float4* __restrict__ 
 // ---- the same walk in two launches (round 3) -------------------------------------------------------------------
 // One launch per level costs four dependent trips to memory (queue length, queue entry, node, slot reservation) plus the
 // launch itself: ~9.5 us a level whatever its width.  Inside a workgroup a level costs one trip (the node) and a block scan.
-//  k_octree_head: the leading levels as in k_octree_top, eight top nodes per workgroup, then up to two more levels from
-//                 queues in LDS (<= 64 and <= 512 nodes: every child of every node fits); the frontier below them goes to the
-//                 global queue, which deals it out evenly again - that is where the subtrees' sizes start to differ.
+//  k_octree_head: the leading levels as in k_octree_top, eight top nodes per workgroup, and in the same breath the two
+//                 levels below them (<= 64 and <= 512 nodes, contiguous id ranges in BFS order, found at set-up): every
+//                 thread tests one node at once, who is reached is settled afterwards in LDS (tests of unreached nodes are
+//                 wasted, but the levels next to the top are nearly always reached, and three dependent rounds of
+//                 load + test become one); the frontier below goes to the global queue, which deals it out evenly
+//                 again - that is where the subtrees' sizes start to differ.
 //  k_octree_tail: a workgroup takes 256 entries of that queue and walks everything below them from a stack in LDS, deepest
 //                 nodes first.  The stack is ordered by level (children are pushed above everything that stays), a level's
 //                 entries are only pushed when all deeper ones fit the same pop, so a level never holds more than 8 x 256
-//                 entries: capacity = 8 x 256 x (levels below the queue's), no spill path needed.  The entries are dealt
+//                 entries: capacity = the queue entries + 8 x 256 x (levels below that are pushed), no spill path needed
+//                 (the deepest level is not pushed: its nodes have no children, reached means emitted).  The entries are dealt
 //                 out in groups of 8 (a cache line of boxes), round-robin over the workgroups: where the cut runs deep,
 //                 EVERY node of a region expands eightfold, and a workgroup holding 256 neighbours walked 9 rounds one
 //                 after another while 60 % of the others were done after one (58 us at cfg 3); dealt out, every
 //                 workgroup walks 2 to 4 rounds (tools/_dbg/lod_tail_sim.py).
-#define GSX_HEAD_NT 512
+#define GSX_HEAD_NT 640          // 64 slots of the top nodes + 64 nodes of the next level + 512 of the one after
 #define GSX_HEAD_G 8u            // top nodes per workgroup: x 8 slots = wave 0
-__global__ __launch_bounds__(GSX_HEAD_NT) void k_octree_head(const float4* __restrict__ a, const float4* __restrict__ b,
-                                                             const uint8_t* __restrict__ leaf, const uint32_t* __restrict__ child,
-                                                             const uint32_t* __restrict__ top_anc, uint32_t top_end, uint32_t last_begin,
+__global__ __launch_bounds__(GSX_HEAD_NT) void k_octree_head(const GsxOctNode* __restrict__ nodes,
+                                                             const uint32_t* __restrict__ parent, const uint32_t* __restrict__ top_anc,
+                                                             const uint4* __restrict__ ranges, uint32_t top_end, uint32_t last_begin,
                                                              uint32_t walk, uint32_t out_level, GsxMat4 vp, float thr, uint8_t stamp,
                                                              uint8_t* __restrict__ emit, uint32_t* __restrict__ queue_out,
                                                              uint32_t* __restrict__ qcount) {
     __shared__ uint32_t s_tmp[GSX_HEAD_NT / 64];
     __shared__ uint32_t s_base;
-    __shared__ uint32_t s_q[2][GSX_HEAD_NT];
-    const uint32_t tid = threadIdx.x;
-    uint32_t fc = 0, nc = 0;
-    if (tid < 64u) {                                    // wave 0: a top node and its ancestors in eight adjacent lanes
+    __shared__ uint8_t s_open4[8], s_open5[64];
+    const uint32_t tid = threadIdx.x, role = tid < 64u ? 0u : (tid < 128u ? 1u : 2u);   // (uniform per wave)
+    const uint4 rg = ranges[blockIdx.x];                // descendants one and two levels below this workgroup's top nodes: (first, count) x 2
+    // Nothing below waits for a test's outcome before it starts the next test: the ids of the descendants are known from the
+    // table, every thread tests its node at once, and who is reached is settled afterwards in LDS.
+    uint32_t id = 0xFFFFFFFFu, pl = 0, cw = 0;
+    bool reached = false, stops = false;
+    if (role == 0u) {                                   // a top node and its ancestors in eight adjacent lanes
         const uint32_t gid = blockIdx.x * 64u + tid, node = gid >> 3, slot = gid & 7u;
-        const uint32_t id = node < top_end ? top_anc[gid] : 0xFFFFFFFFu;
-        const bool stops = id != 0xFFFFFFFFu && gsx_octree_node_stops(a, b, leaf, id, vp, thr);
-        const uint32_t group = static_cast<uint32_t>(__builtin_amdgcn_ballot_w64(stops) >> (tid & ~7u)) & 0xFFu;
-        if (slot == 0u && node < top_end && (group & 0xFEu) == 0u) {   // reached: no ancestor stops
-            if (group & 1u) emit[node] = stamp;
-            else if (node >= last_begin) { const uint32_t cw = child[node]; fc = cw >> 4; nc = cw & 15u; }
+        const uint32_t anc = node < top_end ? top_anc[gid] : 0xFFFFFFFFu;
+        bool st = false;
+        if (anc != 0xFFFFFFFFu) {
+            const GsxOctNode nd = gsx_load_node(nodes, anc);
+            if (slot == 0u) cw = nd.child;
+            st = gsx_node_stops(nd, vp, thr);
+        }
+        const uint32_t group = static_cast<uint32_t>(__builtin_amdgcn_ballot_w64(st) >> (tid & ~7u)) & 0xFFu;
+        if (slot == 0u) {
+            if (node < top_end) { id = node; reached = (group & 0xFEu) == 0u; stops = (group & 1u) != 0u; }
+            s_open4[tid >> 3] = (reached && !stops && node >= last_begin) ? 1 : 0;
+        }
+    } else {
+        const uint32_t j = tid - (role == 1u ? 64u : 128u), cnt = role == 1u ? rg.y : rg.w;
+        if (j < cnt) {
+            id = (role == 1u ? rg.x : rg.z) + j;
+            pl = parent[id] - (role == 1u ? blockIdx.x * GSX_HEAD_G : rg.x);
+            const GsxOctNode nd = gsx_load_node(nodes, id);
+            cw = nd.child;
+            stops = gsx_node_stops(nd, vp, thr);
         }
     }
-    for (uint32_t r = 0; r < walk; ++r) {               // levels walked from LDS: <= 8 children per node (checked at set-up), so 64, then 512 entries
-        uint32_t total;
-        const uint32_t excl = gsx_block_excl_scan<GSX_HEAD_NT>(nc, s_tmp, &total);
-        if (total == 0u) return;                        // (uniform)
-        uint32_t* q = s_q[r & 1u];
-        for (uint32_t k = 0; k < nc; ++k) q[excl + k] = fc + k;
-        __syncthreads();
-        fc = nc = 0;
-        if (tid < total) {
-            const uint32_t i = q[tid];
-            const uint32_t cw = child[i];
-            if (gsx_octree_node_stops(a, b, leaf, i, vp, thr)) emit[i] = stamp;
-            else { fc = cw >> 4; nc = cw & 15u; }
-        }
+    __syncthreads();
+    if (role == 1u && id != 0xFFFFFFFFu) {
+        reached = s_open4[pl & 7u] != 0;
+        s_open5[tid - 64u] = (reached && !stops) ? 1 : 0;
     }
-    uint32_t total;                                     // the frontier: to the global queue
+    __syncthreads();
+    if (role == 2u && id != 0xFFFFFFFFu) reached = s_open5[pl & 63u] != 0;
+    uint32_t fc = 0, nc = 0;
+    if (id != 0xFFFFFFFFu && reached) {
+        if (stops) emit[id] = stamp;
+        else if (role == walk && (role != 0u || id >= last_begin)) { fc = cw >> 4; nc = cw & 15u; }   // the frontier: to the global queue
+    }
+    uint32_t total;
     const uint32_t excl = gsx_block_excl_scan<GSX_HEAD_NT>(nc, s_tmp, &total);
     if (total == 0u) return;                            // (uniform)
     if (tid == 0) s_base = atomicAdd(&qcount[out_level], total);
@@ -216,30 +302,48 @@ __global__ __launch_bounds__(GSX_HEAD_NT) void k_octree_head(const float4* __res
 }
 
 #define GSX_TAIL_NT 256
-#define GSX_TAIL_MAX_DEPTH 6u    // levels below the queue's: 8 x 256 x 6 entries = 48 KB of LDS
-__global__ __launch_bounds__(GSX_TAIL_NT) void k_octree_tail(const float4* __restrict__ a, const float4* __restrict__ b,
-                                                             const uint8_t* __restrict__ leaf, const uint32_t* __restrict__ child,
-                                                             uint32_t n, uint32_t level, uint32_t cap, GsxMat4 vp, float thr, uint8_t stamp,
+#define GSX_TAIL_MAX_DEPTH 6u    // levels below the queue's that get pushed: 8 x 256 x 6 entries = 48 KB of LDS
+__global__ __launch_bounds__(GSX_TAIL_NT) void k_octree_tail(const GsxOctNode* __restrict__ nodes, uint32_t n, uint32_t level, uint32_t last_begin /* first id of the deepest level */,
+                                                             uint32_t cap, GsxMat4 vp, float thr, uint8_t stamp,
                                                              uint8_t* __restrict__ emit, const uint32_t* __restrict__ queue_in,
                                                              const uint32_t* __restrict__ qcount, GsxDevFlags* __restrict__ flags) {
     extern __shared__ uint32_t s_stack[];
     __shared__ uint32_t s_tmp[GSX_TAIL_NT / 64];
     const uint32_t cnt = qcount[level] < n ? qcount[level] : n, tid = threadIdx.x;
-    const uint32_t wgs = (cnt + GSX_TAIL_NT - 1u) / GSX_TAIL_NT;                 // workgroups that have work
+    const uint32_t groups = (cnt + 7u) / 8u;
+    // the grid is what the GPU holds at once (the host knows the level's width, not the queue's length): the workgroups that
+    // have work share the groups evenly, round-robin
+    const uint32_t want = (cnt + GSX_TAIL_NT - 1u) / GSX_TAIL_NT, wgs = want < gridDim.x ? want : gridDim.x;
     if (blockIdx.x >= wgs) return;                      // the whole workgroup is past the queue
-    uint32_t sp = 0;                                    // entries on the stack (uniform)
-    const uint32_t first = ((tid >> 3) * wgs + blockIdx.x) * 8u + (tid & 7u);   // groups of 8 entries, dealt round-robin
-    uint32_t i = first < cnt ? queue_in[first] : 0xFFFFFFFFu;
+    const uint32_t mine = (groups - blockIdx.x + wgs - 1u) / wgs;        // groups blockIdx.x, blockIdx.x + wgs, ...
+    uint32_t sp = mine * 8u;                            // entries on the stack (uniform); the queue entries go on it first
+    if (sp > cap) {                                     // (cannot happen: the host sizes the stack for the level's width)
+        if (tid == 0) atomicOr(&flags->lod_fault, 2u);
+        return;
+    }
+    for (uint32_t e = tid; e < sp; e += GSX_TAIL_NT) {
+        const uint32_t src = ((e >> 3) * wgs + blockIdx.x) * 8u + (e & 7u);
+        s_stack[e] = src < cnt ? queue_in[src] : 0xFFFFFFFFu;
+    }
+    __syncthreads();
     for (;;) {
+        const uint32_t np = sp < GSX_TAIL_NT ? sp : GSX_TAIL_NT;
+        sp -= np;
+        uint32_t i = tid < np ? s_stack[sp + tid] : 0xFFFFFFFFu;   // (the scan's barriers stand between this read and the next push)
         uint32_t fc = 0, nc = 0;
         if (i != 0xFFFFFFFFu && i >= n) {               // (a queue entry that is no node: never follow it)
             atomicOr(&flags->lod_fault, 4u);
             i = 0xFFFFFFFFu;
         }
         if (i != 0xFFFFFFFFu) {
-            const uint32_t cw = child[i];
-            if (gsx_octree_node_stops(a, b, leaf, i, vp, thr)) emit[i] = stamp;
-            else { fc = cw >> 4; nc = cw & 15u; }
+            const GsxOctNode nd = gsx_load_node(nodes, i);
+            if (gsx_node_stops(nd, vp, thr)) emit[i] = stamp;
+            else { fc = nd.child >> 4; nc = nd.child & 15u; }
+        }
+        if (nc != 0u && fc >= last_begin) {             // children in the deepest level are leaves (checked at set-up): reached means emitted
+            for (uint32_t k = 0; k < nc; ++k)
+                if (fc + k < n) emit[fc + k] = stamp;
+            nc = 0u;
         }
         uint32_t total;
         const uint32_t pos = sp + gsx_block_excl_scan<GSX_TAIL_NT>(nc, s_tmp, &total);
@@ -252,9 +356,6 @@ __global__ __launch_bounds__(GSX_TAIL_NT) void k_octree_tail(const float4* __res
         }
         if (sp == 0u) return;                           // (uniform)
         __syncthreads();
-        const uint32_t np = sp < GSX_TAIL_NT ? sp : GSX_TAIL_NT;
-        sp -= np;
-        i = tid < np ? s_stack[sp + tid] : 0xFFFFFFFFu; // (the scan's barriers stand between this read and the next push)
     }
 }
 
@@ -344,41 +445,53 @@ __global__ __launch_bounds__(GSX_CMP_NT) void k_compact_write(const uint8_t* __r
     }
 }
 
-// The same compaction in ONE launch (round 3): at most 512 workgroups, all resident at once (512 threads and 33 KB of LDS
-// each: half the chip's wave slots), every one owning a contiguous span of the flags.  A workgroup counts its span, publishes
-// the count as (cut number << 32 | count) with a device-scope store, sums the counts of the workgroups before it as they
-// appear, then reads its span again (from L2) and writes the ids, staged through LDS so that the stores are whole lines.
-// No chain: a workgroup waits for counts only, and every workgroup publishes its count before it waits for anything.  The
-// wait is bounded (a workgroup that never appears would otherwise hang the grid): on time-out the cut is flagged as failed.
+// The same compaction in ONE launch (round 3): at most 512 workgroups of 512 threads, all resident at once (half the chip's
+// wave slots), every one owning a contiguous span of the flags, every thread up to 8 x 16 consecutive flags of it, kept in
+// registers.  A workgroup counts its span, publishes the count as (cut number << 32 | count) with a device-scope store, sums
+// the counts of the workgroups before it as they appear, and writes its ids (through LDS: whole lines).  No chain: a workgroup waits for counts only,
+// and every workgroup publishes its count before it waits for anything.  The wait is bounded (a workgroup that never
+// appears would otherwise hang the grid): on time-out the cut is flagged as failed.  More than 512 x 512 x 8 x 16 flags
+// (33.5 M) go through the three launches above.
 #define GSX_CP1_NT 512
 #define GSX_CP1_MAXG 512u
+#define GSX_CP1_MAXU 8u
+#define GSX_CP1_STAGE 8192u
 #define GSX_CP1_SPIN_LIMIT (1u << 20)
-__device__ __forceinline__ uint32_t gsx_count_unit(const uint8_t* flags, uint32_t u, uint32_t n, uint32_t match, uint32_t w[4]) {
-    const uint4 v = *reinterpret_cast<const uint4*>(flags + static_cast<uint64_t>(u) * 16u);
-    w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
-    uint32_t cnt = 0;
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        const bool on = ((w[j >> 2] >> (8 * (j & 3))) & 0xFFu) == match && (u * 16u + j) < n;
-        cnt += on ? 1u : 0u;
-    }
-    return cnt;
-}
-
 __global__ __launch_bounds__(GSX_CP1_NT) void k_compact_onepass(const uint8_t* __restrict__ flags, uint32_t n, uint32_t match,
-                                                                uint32_t units_per_wg, uint64_t* __restrict__ agg, uint32_t seq,
-                                                                uint32_t* __restrict__ out, uint32_t* __restrict__ m_out,
+                                                                uint32_t upt /* 16-flag units per thread, <= 8 */, uint64_t* __restrict__ agg,
+                                                                uint32_t seq, uint32_t* __restrict__ out, uint32_t* __restrict__ m_out,
                                                                 uint32_t* __restrict__ qcount, GsxDevFlags* __restrict__ dflags) {
     __shared__ uint32_t s_tmp[GSX_CP1_NT / 64];
     __shared__ uint32_t s_prefix;
-    __shared__ uint32_t s_ids[GSX_CP1_NT * 16];
+    __shared__ uint32_t s_ids[GSX_CP1_STAGE];
     const uint32_t tid = threadIdx.x, units = (n + 15u) / 16u;
-    const uint32_t u0 = blockIdx.x * units_per_wg, u1 = u0 + units_per_wg < units ? u0 + units_per_wg : units;
+    const uint32_t u0 = (blockIdx.x * GSX_CP1_NT + tid) * upt;      // this thread's first unit
     if (blockIdx.x == 0 && qcount && tid <= GSX_LOD_MAX_LEVELS + 1) qcount[tid] = 0u;   // the octree cut's level counters, for the next cut
-    uint32_t w[4], cnt = 0;
-    for (uint32_t u = u0 + tid; u < u1; u += GSX_CP1_NT) cnt += gsx_count_unit(flags, u, n, match, w);
+    // per 4 flag bytes one word t with bit 8 b + 7 set where byte b matches (exact per byte: no borrow between bytes)
+    uint32_t t[GSX_CP1_MAXU][4];
+    uint32_t cnt = 0;
+    const uint32_t match4 = match * 0x01010101u;
+#pragma unroll
+    for (uint32_t k = 0; k < GSX_CP1_MAXU; ++k) {
+        uint4 w = make_uint4(match4 ^ 0x01010101u, match4 ^ 0x01010101u, match4 ^ 0x01010101u, match4 ^ 0x01010101u);   // (matches nowhere)
+        if (k < upt && u0 + k < units) w = *reinterpret_cast<const uint4*>(flags + static_cast<uint64_t>(u0 + k) * 16u);
+        const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t y = ww[q] ^ match4;
+            t[k][q] = ~(((y & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | y | 0x7F7F7F7Fu);
+        }
+        if (k < upt && (u0 + k) * 16u + 16u > n) {      // the unit that holds flag n - 1 (and those behind): bytes from n on never count
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint32_t first = (u0 + k) * 16u + 4u * q, valid = first >= n ? 0u : (n - first >= 4u ? 4u : n - first);
+                t[k][q] &= valid >= 4u ? 0xFFFFFFFFu : ((1u << (8u * valid)) - 1u);
+            }
+        }
+        cnt += __popc(t[k][0]) + __popc(t[k][1]) + __popc(t[k][2]) + __popc(t[k][3]);
+    }
     uint32_t total;
-    gsx_block_excl_scan<GSX_CP1_NT>(cnt, s_tmp, &total);
+    const uint32_t excl = gsx_block_excl_scan<GSX_CP1_NT>(cnt, s_tmp, &total);
     if (tid == 0) __hip_atomic_store(&agg[blockIdx.x], (static_cast<uint64_t>(seq) << 32) | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (tid < 64u) {
         uint32_t sum = 0;
@@ -398,41 +511,46 @@ __global__ __launch_bounds__(GSX_CP1_NT) void k_compact_onepass(const uint8_t* _
         if (tid == 0) s_prefix = sum;
     }
     __syncthreads();
-    uint32_t run = s_prefix;
-    if (blockIdx.x == gridDim.x - 1 && tid == 0) *m_out = run + total;
-    for (uint32_t ub = u0; ub < u1; ub += GSX_CP1_NT) {             // (uniform)
-        const uint32_t u = ub + tid;
-        w[0] = w[1] = w[2] = w[3] = 0u;
-        const uint32_t c = u < u1 ? gsx_count_unit(flags, u, n, match, w) : 0u;
-        uint32_t tile_total;
-        uint32_t pos = gsx_block_excl_scan<GSX_CP1_NT>(c, s_tmp, &tile_total);
-        if (c) {
+    if (blockIdx.x == gridDim.x - 1 && tid == 0) *m_out = s_prefix + total;
+    const uint32_t run = s_prefix;
+    if (run + total > n) return;                        // (only after a timed-out wait: never write past the list; uniform)
+    // the ids go out through LDS, GSX_CP1_STAGE at a time, so that the stores are whole lines (a thread's own ids are few and
+    // scattered over 48+ flags: stored straight from registers the launch took 22 us instead of 17)
+    for (uint32_t win = 0; win < total; win += GSX_CP1_STAGE) {     // (uniform; one turn unless more than a third of the flags are set)
+        uint32_t pos = excl - win;                      // (unsigned: an id below the window wraps to huge and is skipped)
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const bool on = ((w[j >> 2] >> (8 * (j & 3))) & 0xFFu) == match && (u * 16u + j) < n;
-                if (on) s_ids[pos++] = u * 16u + j;
+        for (uint32_t k = 0; k < GSX_CP1_MAXU; ++k) {
+            if (k < upt) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    uint32_t bits = t[k][q];
+                    while (bits) {                      // one turn per set flag (the wave: as many as its fullest lane has)
+                        const uint32_t b = static_cast<uint32_t>(__ffs(static_cast<int>(bits))) - 1u;
+                        if (pos < GSX_CP1_STAGE) s_ids[pos] = (u0 + k) * 16u + 4u * q + (b >> 3);
+                        ++pos;
+                        bits &= bits - 1u;
+                    }
+                }
             }
         }
         __syncthreads();
-        for (uint32_t k = tid; k < tile_total; k += GSX_CP1_NT) out[run + k] = s_ids[k];
-        run += tile_total;
+        const uint32_t m = total - win < GSX_CP1_STAGE ? total - win : GSX_CP1_STAGE;
+        for (uint32_t k = tid; k < m; k += GSX_CP1_NT) out[run + win + k] = s_ids[k];
         __syncthreads();
     }
 }
 
 // ids whose flag byte equals `match`, ascending
 static int compact(gsx_ctx* c, uint32_t n, uint32_t match = 1u) {
-    if (!c->opt_lod_walk) {
-        const uint32_t units = gsx_div_up(n, 16u);
-        uint32_t g = gsx_div_up(units, static_cast<uint32_t>(GSX_CP1_NT));
-        g = g < 1u ? 1u : (g > GSX_CP1_MAXG ? GSX_CP1_MAXG : g);
-        const uint32_t per = gsx_div_up(gsx_div_up(units, g), static_cast<uint32_t>(GSX_CP1_NT)) * GSX_CP1_NT;   // whole tiles
-        g = per ? gsx_div_up(units, per) : 1u;
+    const uint32_t units = gsx_div_up(n, 16u);
+    const uint32_t upt = units ? gsx_div_up(units, GSX_CP1_NT * GSX_CP1_MAXG) : 1u;      // 16-flag units per thread
+    if (!c->opt_lod_walk && upt <= GSX_CP1_MAXU) {
+        const uint32_t g = units ? gsx_div_up(units, GSX_CP1_NT * upt) : 1u;
         if (++c->lod_seq == 0u) {                       // cut numbers wrapped: forget the old counts
             GSX_HIP(c, hipMemsetAsync(c->lod_agg, 0, GSX_CP1_MAXG * sizeof(uint64_t), c->sel_stream));
             c->lod_seq = 1u;
         }
-        hipLaunchKernelGGL(k_compact_onepass, dim3(g), dim3(GSX_CP1_NT), 0, c->sel_stream, c->lod_emit, n, match, per, c->lod_agg,
+        hipLaunchKernelGGL(k_compact_onepass, dim3(g), dim3(GSX_CP1_NT), 0, c->sel_stream, c->lod_emit, n, match, upt, c->lod_agg,
                            c->lod_seq, c->sel_idx, c->m_dev, c->lod_qcount, c->flags);
         GSX_HIP(c, hipGetLastError());
         return GSX_OK;
@@ -465,8 +583,8 @@ int gsx_launch_select_octree(gsx_ctx* c, const float vp[16], float thr) {
         if (c->opt_lod_walk == 0 && c->lod_max_children <= 8u) {
             const uint32_t walk = c->lod_levels - top < 2u ? c->lod_levels - top : 2u;
             l = top + walk;
-            hipLaunchKernelGGL(k_octree_head, dim3(gsx_div_up(lv.start[top], GSX_HEAD_G)), dim3(GSX_HEAD_NT), 0, c->sel_stream, c->lod_a,
-                               c->lod_b, c->lod_leaf, c->lod_child, c->lod_top_anc, lv.start[top], lv.start[top - 1u], walk, l, m, thr,
+            hipLaunchKernelGGL(k_octree_head, dim3(gsx_div_up(lv.start[top], GSX_HEAD_G)), dim3(GSX_HEAD_NT), 0, c->sel_stream,
+                               reinterpret_cast<const GsxOctNode*>(c->lod_node), c->lod_parent, c->lod_top_anc, c->lod_head_ranges, lv.start[top], lv.start[top - 1u], walk, l, m, thr,
                                static_cast<uint8_t>(match), c->lod_emit, c->lod_queue[l & 1u], c->lod_qcount);
         } else {
             hipLaunchKernelGGL(k_octree_top, dim3(gsx_div_up(lv.start[top] * 8u, GSX_TOP_NT)), dim3(GSX_TOP_NT), 0, c->sel_stream, c->lod_a, c->lod_b,
@@ -476,13 +594,19 @@ int gsx_launch_select_octree(gsx_ctx* c, const float vp[16], float thr) {
         for (; l < c->lod_levels; ++l) {
             // (the queue's length is only known on the device: the grid covers the level, workgroups past the queue leave at once)
             const uint32_t width = lv.start[l + 1] - lv.start[l];
-            const uint32_t below = c->lod_levels - 1u - l;
-            if (c->opt_lod_walk == 0 && c->lod_max_children <= 8u && below <= GSX_TAIL_MAX_DEPTH) {   // everything from here down in one launch
-                const uint32_t cap = 8u * GSX_TAIL_NT * (below ? below : 1u);
-                hipLaunchKernelGGL(k_octree_tail, dim3(gsx_div_up(width, GSX_TAIL_NT)), dim3(GSX_TAIL_NT), cap * sizeof(uint32_t), c->sel_stream,
-                                   c->lod_a, c->lod_b, c->lod_leaf, c->lod_child, n, l, cap, m, thr, static_cast<uint8_t>(match), c->lod_emit,
-                                   c->lod_queue[l & 1u], c->lod_qcount, c->flags);
-                break;
+            // levels below this one whose nodes go on the stack: the deepest level's are emitted when their parent is expanded
+            const uint32_t below = c->lod_levels - 1u - l, pushed = (below && c->lod_deepest_leaf) ? below - 1u : below;
+            if (c->opt_lod_walk == 0 && c->lod_max_children <= 8u && pushed <= GSX_TAIL_MAX_DEPTH) {   // everything from here down in one launch
+                // one workgroup per 256 nodes of the level.  (A grid bounded by what the GPU holds at once, every workgroup taking
+                // its share of the queue, measured slower: 29.7 against 24.9 us - finished workgroups make room as they go.)
+                const uint32_t grid = gsx_div_up(width, GSX_TAIL_NT);
+                const uint32_t cap = std::max<uint32_t>(GSX_TAIL_NT, gsx_div_up(gsx_div_up(width, 8u), grid) * 8u) + 8u * GSX_TAIL_NT * pushed;
+                if (cap * sizeof(uint32_t) <= (64u << 10)) {
+                    hipLaunchKernelGGL(k_octree_tail, dim3(grid), dim3(GSX_TAIL_NT), cap * sizeof(uint32_t), c->sel_stream,
+                                       reinterpret_cast<const GsxOctNode*>(c->lod_node), n, l, c->lod_deepest_leaf ? lv.start[c->lod_levels - 1u] : n, cap, m, thr,
+                                       static_cast<uint8_t>(match), c->lod_emit, c->lod_queue[l & 1u], c->lod_qcount, c->flags);
+                    break;
+                }
             }
             if (width <= (256u << 10))
                 hipLaunchKernelGGL(k_octree_level<256>, dim3(gsx_div_up(width, 256)), dim3(256), 0, c->sel_stream, c->lod_a, c->lod_b,
