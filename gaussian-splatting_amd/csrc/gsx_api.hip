@@ -77,8 +77,8 @@ int alloc_scene(gsx_ctx* c, uint64_t n) {
     const uint64_t fl = (n + 15) / 16 * 16 + 16;
     if ((rc = dev_alloc(c, &c->lod_stop, fl)) || (rc = dev_alloc(c, &c->lod_emit, fl))) return rc;
     if ((rc = dev_alloc(c, &c->lod_block_sums, n / 4096 + 2))) return rc;
-    if ((rc = dev_alloc(c, &c->lod_agg, 512))) return rc;
-    GSX_HIP(c, hipMemset(c->lod_agg, 0, 512 * sizeof(uint64_t)));
+    if ((rc = dev_alloc(c, &c->lod_agg, 1024))) return rc;      // (>= GSX_CP1_MAXG words)
+    GSX_HIP(c, hipMemset(c->lod_agg, 0, 1024 * sizeof(uint64_t)));
     c->lod_seq = 0;
     c->lod_cap = n;
     return GSX_OK;

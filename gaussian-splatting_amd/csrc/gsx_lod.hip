@@ -445,53 +445,61 @@ __global__ __launch_bounds__(GSX_CMP_NT) void k_compact_write(const uint8_t* __r
     }
 }
 
-// The same compaction in ONE launch (round 3): at most 512 workgroups of 512 threads, all resident at once (half the chip's
-// wave slots), every one owning a contiguous span of the flags, every thread up to 8 x 16 consecutive flags of it, kept in
-// registers.  A workgroup counts its span, publishes the count as (cut number << 32 | count) with a device-scope store, sums
-// the counts of the workgroups before it as they appear, and writes its ids (through LDS: whole lines).  No chain: a workgroup waits for counts only,
-// and every workgroup publishes its count before it waits for anything.  The wait is bounded (a workgroup that never
-// appears would otherwise hang the grid): on time-out the cut is flagged as failed.  More than 512 x 512 x 8 x 16 flags
-// (33.5 M) go through the three launches above.
+// The same compaction in ONE launch (round 3): workgroups of 512 threads, each owning up to 8 tiles of 512 x 16 consecutive
+// flags (a thread: one 16-byte unit per tile, kept in registers as match masks).  A workgroup counts its span, publishes the
+// count as (cut number << 32 | count) with a device-scope store, sums the counts of the workgroups before it as they
+// appear, and writes its ids.  No chain: a workgroup waits for counts only, and every workgroup publishes its count before
+// it waits for anything; it waits for LOWER-numbered workgroups only, which the dispatcher starts first, and the wait is
+// bounded all the same (on time-out the cut is flagged as failed instead of hanging the grid).  Measured on its own
+// (tools/compactbench.hip, 8.48 M flags, 17 % set): 12.7 us against 18.4 us for the three launches; of that a workgroup
+// spends ~1.5 us loading, ~1.5 us in its scans, ~3 us until the counts before it are visible and < 1 us writing.  Ids
+// staged through LDS for whole-line stores were slower (15-16 us), a thread owning consecutive units (one scan) as well
+// (14.5-16 us), 256- and 1024-thread workgroups too.  More than 768 x 512 x 8 x 16 flags (50 M) go through the three launches.
 #define GSX_CP1_NT 512
-#define GSX_CP1_MAXG 512u
+#define GSX_CP1_MAXG 768u
 #define GSX_CP1_MAXU 8u
-#define GSX_CP1_STAGE 8192u
 #define GSX_CP1_SPIN_LIMIT (1u << 20)
 __global__ __launch_bounds__(GSX_CP1_NT) void k_compact_onepass(const uint8_t* __restrict__ flags, uint32_t n, uint32_t match,
-                                                                uint32_t upt /* 16-flag units per thread, <= 8 */, uint64_t* __restrict__ agg,
+                                                                uint32_t upt /* tiles per workgroup, <= 8 */, uint64_t* __restrict__ agg,
                                                                 uint32_t seq, uint32_t* __restrict__ out, uint32_t* __restrict__ m_out,
                                                                 uint32_t* __restrict__ qcount, GsxDevFlags* __restrict__ dflags) {
     __shared__ uint32_t s_tmp[GSX_CP1_NT / 64];
     __shared__ uint32_t s_prefix;
-    __shared__ uint32_t s_ids[GSX_CP1_STAGE];
     const uint32_t tid = threadIdx.x, units = (n + 15u) / 16u;
-    const uint32_t u0 = (blockIdx.x * GSX_CP1_NT + tid) * upt;      // this thread's first unit
     if (blockIdx.x == 0 && qcount && tid <= GSX_LOD_MAX_LEVELS + 1) qcount[tid] = 0u;   // the octree cut's level counters, for the next cut
     // per 4 flag bytes one word t with bit 8 b + 7 set where byte b matches (exact per byte: no borrow between bytes)
-    uint32_t t[GSX_CP1_MAXU][4];
-    uint32_t cnt = 0;
+    uint32_t t[GSX_CP1_MAXU][4], tile_cnt[GSX_CP1_MAXU];
     const uint32_t match4 = match * 0x01010101u;
 #pragma unroll
     for (uint32_t k = 0; k < GSX_CP1_MAXU; ++k) {
+        const uint32_t u = (blockIdx.x * upt + k) * GSX_CP1_NT + tid;           // this thread's unit of tile k
         uint4 w = make_uint4(match4 ^ 0x01010101u, match4 ^ 0x01010101u, match4 ^ 0x01010101u, match4 ^ 0x01010101u);   // (matches nowhere)
-        if (k < upt && u0 + k < units) w = *reinterpret_cast<const uint4*>(flags + static_cast<uint64_t>(u0 + k) * 16u);
+        if (k < upt && u < units) w = *reinterpret_cast<const uint4*>(flags + static_cast<uint64_t>(u) * 16u);
         const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const uint32_t y = ww[q] ^ match4;
             t[k][q] = ~(((y & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | y | 0x7F7F7F7Fu);
         }
-        if (k < upt && (u0 + k) * 16u + 16u > n) {      // the unit that holds flag n - 1 (and those behind): bytes from n on never count
+        if (k < upt && u * 16u + 16u > n) {             // the unit that holds flag n - 1 (and those behind): bytes from n on never count
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const uint32_t first = (u0 + k) * 16u + 4u * q, valid = first >= n ? 0u : (n - first >= 4u ? 4u : n - first);
+                const uint32_t first = u * 16u + 4u * q, valid = first >= n ? 0u : (n - first >= 4u ? 4u : n - first);
                 t[k][q] &= valid >= 4u ? 0xFFFFFFFFu : ((1u << (8u * valid)) - 1u);
             }
         }
-        cnt += __popc(t[k][0]) + __popc(t[k][1]) + __popc(t[k][2]) + __popc(t[k][3]);
+        tile_cnt[k] = __popc(t[k][0]) + __popc(t[k][1]) + __popc(t[k][2]) + __popc(t[k][3]);
     }
-    uint32_t total;
-    const uint32_t excl = gsx_block_excl_scan<GSX_CP1_NT>(cnt, s_tmp, &total);
+    uint32_t total = 0, tile_excl[GSX_CP1_MAXU];
+#pragma unroll
+    for (uint32_t k = 0; k < GSX_CP1_MAXU; ++k) {
+        tile_excl[k] = 0;
+        if (k < upt) {                                  // (uniform)
+            uint32_t tile_total;
+            tile_excl[k] = total + gsx_block_excl_scan<GSX_CP1_NT>(tile_cnt[k], s_tmp, &tile_total);
+            total += tile_total;
+        }
+    }
     if (tid == 0) __hip_atomic_store(&agg[blockIdx.x], (static_cast<uint64_t>(seq) << 32) | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (tid < 64u) {
         uint32_t sum = 0;
@@ -511,39 +519,31 @@ __global__ __launch_bounds__(GSX_CP1_NT) void k_compact_onepass(const uint8_t* _
         if (tid == 0) s_prefix = sum;
     }
     __syncthreads();
-    if (blockIdx.x == gridDim.x - 1 && tid == 0) *m_out = s_prefix + total;
     const uint32_t run = s_prefix;
-    if (run + total > n) return;                        // (only after a timed-out wait: never write past the list; uniform)
-    // the ids go out through LDS, GSX_CP1_STAGE at a time, so that the stores are whole lines (a thread's own ids are few and
-    // scattered over 48+ flags: stored straight from registers the launch took 22 us instead of 17)
-    for (uint32_t win = 0; win < total; win += GSX_CP1_STAGE) {     // (uniform; one turn unless more than a third of the flags are set)
-        uint32_t pos = excl - win;                      // (unsigned: an id below the window wraps to huge and is skipped)
+    if (blockIdx.x == gridDim.x - 1 && tid == 0) *m_out = run + total;
+    if (run + total > n) return;                        // (only after a timed-out wait: never write past the list)
 #pragma unroll
-        for (uint32_t k = 0; k < GSX_CP1_MAXU; ++k) {
-            if (k < upt) {
+    for (uint32_t k = 0; k < GSX_CP1_MAXU; ++k) {
+        if (k < upt) {
+            const uint32_t u = (blockIdx.x * upt + k) * GSX_CP1_NT + tid;
+            uint32_t pos = run + tile_excl[k];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    uint32_t bits = t[k][q];
-                    while (bits) {                      // one turn per set flag (the wave: as many as its fullest lane has)
-                        const uint32_t b = static_cast<uint32_t>(__ffs(static_cast<int>(bits))) - 1u;
-                        if (pos < GSX_CP1_STAGE) s_ids[pos] = (u0 + k) * 16u + 4u * q + (b >> 3);
-                        ++pos;
-                        bits &= bits - 1u;
-                    }
+            for (int q = 0; q < 4; ++q) {
+                uint32_t bits = t[k][q];
+                while (bits) {                          // one turn per set flag (the wave: as many as its fullest lane has)
+                    const uint32_t b = static_cast<uint32_t>(__ffs(static_cast<int>(bits))) - 1u;
+                    out[pos++] = u * 16u + 4u * q + (b >> 3);
+                    bits &= bits - 1u;
                 }
             }
         }
-        __syncthreads();
-        const uint32_t m = total - win < GSX_CP1_STAGE ? total - win : GSX_CP1_STAGE;
-        for (uint32_t k = tid; k < m; k += GSX_CP1_NT) out[run + win + k] = s_ids[k];
-        __syncthreads();
     }
 }
 
 // ids whose flag byte equals `match`, ascending
 static int compact(gsx_ctx* c, uint32_t n, uint32_t match = 1u) {
     const uint32_t units = gsx_div_up(n, 16u);
-    const uint32_t upt = units ? gsx_div_up(units, GSX_CP1_NT * GSX_CP1_MAXG) : 1u;      // 16-flag units per thread
+    const uint32_t upt = units ? gsx_div_up(units, GSX_CP1_NT * GSX_CP1_MAXG) : 1u;      // tiles of 512 units per workgroup
     if (!c->opt_lod_walk && upt <= GSX_CP1_MAXU) {
         const uint32_t g = units ? gsx_div_up(units, GSX_CP1_NT * upt) : 1u;
         if (++c->lod_seq == 0u) {                       // cut numbers wrapped: forget the old counts
