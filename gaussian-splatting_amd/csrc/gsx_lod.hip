@@ -303,17 +303,18 @@ __global__ __launch_bounds__(GSX_HEAD_NT) void k_octree_head(const GsxOctNode* _
 
 #define GSX_TAIL_NT 256
 #define GSX_TAIL_MAX_DEPTH 6u    // levels below the queue's that get pushed: 8 x 256 x 6 entries = 48 KB of LDS
-__global__ __launch_bounds__(GSX_TAIL_NT) void k_octree_tail(const GsxOctNode* __restrict__ nodes, uint32_t n, uint32_t level, uint32_t last_begin /* first id of the deepest level */,
+template <int TNT>
+__global__ __launch_bounds__(TNT) void k_octree_tail(const GsxOctNode* __restrict__ nodes, uint32_t n, uint32_t level, uint32_t last_begin /* first id of the deepest level */,
                                                              uint32_t cap, GsxMat4 vp, float thr, uint8_t stamp,
                                                              uint8_t* __restrict__ emit, const uint32_t* __restrict__ queue_in,
                                                              const uint32_t* __restrict__ qcount, GsxDevFlags* __restrict__ flags) {
     extern __shared__ uint32_t s_stack[];
-    __shared__ uint32_t s_tmp[GSX_TAIL_NT / 64];
+    __shared__ uint32_t s_tmp[TNT / 64];
     const uint32_t cnt = qcount[level] < n ? qcount[level] : n, tid = threadIdx.x;
     const uint32_t groups = (cnt + 7u) / 8u;
     // the grid is what the GPU holds at once (the host knows the level's width, not the queue's length): the workgroups that
     // have work share the groups evenly, round-robin
-    const uint32_t want = (cnt + GSX_TAIL_NT - 1u) / GSX_TAIL_NT, wgs = want < gridDim.x ? want : gridDim.x;
+    const uint32_t want = (cnt + TNT - 1u) / TNT, wgs = want < gridDim.x ? want : gridDim.x;
     if (blockIdx.x >= wgs) return;                      // the whole workgroup is past the queue
     const uint32_t mine = (groups - blockIdx.x + wgs - 1u) / wgs;        // groups blockIdx.x, blockIdx.x + wgs, ...
     uint32_t sp = mine * 8u;                            // entries on the stack (uniform); the queue entries go on it first
@@ -321,13 +322,13 @@ __global__ __launch_bounds__(GSX_TAIL_NT) void k_octree_tail(const GsxOctNode* _
         if (tid == 0) atomicOr(&flags->lod_fault, 2u);
         return;
     }
-    for (uint32_t e = tid; e < sp; e += GSX_TAIL_NT) {
+    for (uint32_t e = tid; e < sp; e += TNT) {
         const uint32_t src = ((e >> 3) * wgs + blockIdx.x) * 8u + (e & 7u);
         s_stack[e] = src < cnt ? queue_in[src] : 0xFFFFFFFFu;
     }
     __syncthreads();
     for (;;) {
-        const uint32_t np = sp < GSX_TAIL_NT ? sp : GSX_TAIL_NT;
+        const uint32_t np = sp < TNT ? sp : TNT;
         sp -= np;
         uint32_t i = tid < np ? s_stack[sp + tid] : 0xFFFFFFFFu;   // (the scan's barriers stand between this read and the next push)
         uint32_t fc = 0, nc = 0;
@@ -346,7 +347,7 @@ __global__ __launch_bounds__(GSX_TAIL_NT) void k_octree_tail(const GsxOctNode* _
             nc = 0u;
         }
         uint32_t total;
-        const uint32_t pos = sp + gsx_block_excl_scan<GSX_TAIL_NT>(nc, s_tmp, &total);
+        const uint32_t pos = sp + gsx_block_excl_scan<TNT>(nc, s_tmp, &total);
         for (uint32_t k = 0; k < nc; ++k)
             if (pos + k < cap) s_stack[pos + k] = fc + k;
         sp += total;
@@ -599,12 +600,13 @@ int gsx_launch_select_octree(gsx_ctx* c, const float vp[16], float thr) {
             if (c->opt_lod_walk == 0 && c->lod_max_children <= 8u && pushed <= GSX_TAIL_MAX_DEPTH) {   // everything from here down in one launch
                 // one workgroup per 256 nodes of the level.  (A grid bounded by what the GPU holds at once, every workgroup taking
                 // its share of the queue, measured slower: 29.7 against 24.9 us - finished workgroups make room as they go.)
+                // (128- and 512-thread workgroups measured the same and slower: 20.8 / 21.1 / 23.4 us)
                 const uint32_t grid = gsx_div_up(width, GSX_TAIL_NT);
                 const uint32_t cap = std::max<uint32_t>(GSX_TAIL_NT, gsx_div_up(gsx_div_up(width, 8u), grid) * 8u) + 8u * GSX_TAIL_NT * pushed;
                 if (cap * sizeof(uint32_t) <= (64u << 10)) {
-                    hipLaunchKernelGGL(k_octree_tail, dim3(grid), dim3(GSX_TAIL_NT), cap * sizeof(uint32_t), c->sel_stream,
-                                       reinterpret_cast<const GsxOctNode*>(c->lod_node), n, l, c->lod_deepest_leaf ? lv.start[c->lod_levels - 1u] : n, cap, m, thr,
-                                       static_cast<uint8_t>(match), c->lod_emit, c->lod_queue[l & 1u], c->lod_qcount, c->flags);
+                    hipLaunchKernelGGL(k_octree_tail<GSX_TAIL_NT>, dim3(grid), dim3(GSX_TAIL_NT), cap * sizeof(uint32_t), c->sel_stream,
+                                       reinterpret_cast<const GsxOctNode*>(c->lod_node), n, l, c->lod_deepest_leaf ? lv.start[c->lod_levels - 1u] : n, cap,
+                                       m, thr, static_cast<uint8_t>(match), c->lod_emit, c->lod_queue[l & 1u], c->lod_qcount, c->flags);
                     break;
                 }
             }

@@ -488,6 +488,122 @@ def test_octree_non_bfs_layout_uses_the_general_cut(gsx_fresh, oracle):
             assert m == len(want) and np.array_equal(gsx.selection(), want)
 
 
+def _random_bfs_tree(rng, levels, first_width, grow, leaf_everywhere=True):
+    """A BFS-numbered tree with nested boxes: level l has about first_width * grow^l nodes, every node 0..8 children."""
+    parent, center, half, lvl = [0xFFFFFFFF], [np.zeros(3)], [np.full(3, 4.0)], [0]
+    begin, end = 0, 1
+    for l in range(1, levels):
+        want = max(1, int(first_width * grow ** l))
+        kids = np.zeros(end - begin, int)
+        for _ in range(want):
+            kids[rng.integers(0, end - begin)] += 1
+        kids = np.minimum(kids, 8)
+        if kids.sum() == 0:
+            kids[0] = 1
+        for j, k in enumerate(kids):
+            p = begin + j
+            for q in range(k):
+                off = np.array([(q & 1) - 0.5, ((q >> 1) & 1) - 0.5, ((q >> 2) & 1) - 0.5]) * half[p]
+                parent.append(p); center.append(center[p] + off * rng.uniform(0.6, 1.0)); half.append(half[p] * rng.uniform(0.35, 0.55, 3)); lvl.append(l)
+        begin, end = end, len(parent)
+    parent = np.array(parent, np.uint32)
+    n = len(parent)
+    has_child = np.zeros(n, bool)
+    has_child[parent[1:]] = True
+    leaf = (~has_child).astype(np.uint8)
+    if not leaf_everywhere:
+        leaf[np.array(lvl) == levels - 1] = 0             # childless nodes that are not marked as leaves: emitted only when small enough
+    return parent, np.array(center, np.float32), np.array(half, np.float32), leaf
+
+
+@pytest.mark.parametrize("shape", ["one node", "two levels", "wide and shallow", "deep", "deepest level not leaves", "very deep"])
+def test_octree_cut_shapes_match_the_ancestor_walk(gsx_fresh, oracle, shape):
+    """The three-launch cut (head, tail, one-launch compaction) against the ancestor-walk kernels and the per-level launches on
+    trees whose shape exercises every branch of the launch logic: no level below the top, one, two; more levels below the
+    queue than the LDS stack is sized for (per-level launches first, then the tail); a deepest level that is not all
+    leaves (its nodes are then tested like any other)."""
+    gsx = gsx_fresh
+    rng = np.random.default_rng(len(shape))
+    levels, width, grow, leafy = {"one node": (1, 1, 1, True), "two levels": (2, 1, 8, True), "wide and shallow": (7, 1, 5.5, True),
+                                  "deep": (12, 6, 2.2, True), "deepest level not leaves": (9, 4, 3.0, False),
+                                  "very deep": (20, 40, 1.45, True)}[shape]
+    parent, center, half, leaf = _random_bfs_tree(rng, levels, width, grow, leafy)
+    n = len(parent)
+    splats = np.zeros((n, 20), np.float32)
+    splats[:, 0] = splats[:, 5] = splats[:, 10] = 0.01
+    splats[:, 15] = 1.0
+    splats[:, 16:19] = center
+    gsx.upload(splats)
+    gsx.set_lod_octree(center, half, parent, leaf)
+    world, _ = oracle.orbit_world(9.0, (0.0, 1.0, 0.0), 0.3, 1)
+    view, proj, vp, cam = oracle.camera(world, 45.0, 16 / 9)
+    for thr in (10.0, 0.5, 0.05, 0.004, 0.0003, 0.00002, 0.0):
+        gsx.set_option("lod_walk", 1)
+        m_ref = gsx.select_octree(vp, thr)
+        ref = gsx.selection()
+        for walk in (2, 0, 0):                            # (twice: the second cut reuses the cleared counters and the next stamp)
+            gsx.set_option("lod_walk", walk)
+            assert gsx.select_octree(vp, thr) == m_ref, (shape, thr, walk)
+            assert np.array_equal(gsx.selection(), ref), (shape, thr, walk)
+    gsx.set_option("lod_walk", 0)
+
+
+def test_octree_cut_thresholds_on_node_areas(gsx_fresh, oracle):
+    """The walk decides `screen_area < threshold` from a cheap evaluation with an error bound and only evaluates the exactly
+    rounded area when that is too close to call.  Thresholds placed ON the exact area of a node (the node must not stop),
+    one ulp above (it must) and one below, for nodes of every level and boxes near and behind the camera plane: the cut
+    must be the CPU oracle's (oracle/orc.c, Octree.cpp:189-216) every time."""
+    gsx = gsx_fresh
+    rng = np.random.default_rng(17)
+    parent, center, half, leaf = _random_bfs_tree(rng, 8, 2, 3.2)
+    n = len(parent)
+    nc = np.bincount(parent[1:], minlength=n).astype(np.uint32)
+    fc = np.zeros(n, np.uint32)
+    kids = np.flatnonzero(nc)
+    fc[kids] = np.searchsorted(parent[1:], kids).astype(np.uint32) + 1
+    splats = np.zeros((n, 20), np.float32)
+    splats[:, 0] = splats[:, 5] = splats[:, 10] = 0.01
+    splats[:, 15] = 1.0
+    splats[:, 16:19] = center
+    gsx.upload(splats)
+    gsx.set_lod_octree(center, half, parent, leaf)
+    checked = 0
+    for dist in (9.0, 2.5, 0.7):                          # (0.7: the camera stands inside the tree's box, corners behind it)
+        world, _ = oracle.orbit_world(dist, (0.0, 1.0, 0.0), 0.4, 2)
+        view, proj, vp, cam = oracle.camera(world, 45.0, 16 / 9)
+        for i in rng.choice(np.flatnonzero(leaf == 0), 40, replace=False):
+            area = np.float32(oracle.bb_screen_area(center[i], half[i], vp))
+            if not np.isfinite(area) or area <= 0:
+                continue
+            for thr in (area, np.nextafter(area, np.float32(np.inf)), np.nextafter(area, np.float32(0))):
+                want = oracle.octree_cut(center, half, fc, nc, vp, float(thr))
+                assert gsx.select_octree(vp, float(thr)) == len(want), (dist, i, thr)
+                assert np.array_equal(gsx.selection(), np.sort(want)), (dist, i, thr)
+                checked += 1
+    assert checked > 200
+
+
+def test_one_launch_compaction_edges(gsx_fresh, oracle):
+    """Selection lists through the one-launch compaction: sizes that are not multiples of 16 or of a tile, nothing selected,
+    everything selected (more ids than a workgroup's flags are sparse), the last id alone; against the three launches."""
+    gsx = gsx_fresh
+    rng = np.random.default_rng(5)
+    for n in (1, 15, 16, 17, 8191, 8193, 300_001, 2_500_003):
+        splats = np.zeros((n, 20), np.float32)
+        splats[:, 0] = splats[:, 5] = splats[:, 10] = 0.01
+        splats[:, 15] = 1.0
+        splats[:, 16:19] = rng.uniform(-1, 1, (n, 3))
+        gsx.upload(splats)
+        picks = [np.zeros(0, np.uint32), np.arange(n, dtype=np.uint32), np.array([n - 1], np.uint32),
+                 np.flatnonzero(rng.random(n) < 0.13).astype(np.uint32), np.flatnonzero(rng.random(n) < 0.9).astype(np.uint32)]
+        for pick in picks:
+            for walk in (0, 1):
+                gsx.set_option("lod_walk", walk)
+                gsx.select_list(rng.permutation(pick))
+                assert np.array_equal(gsx.selection(), pick), (n, len(pick), walk)
+    gsx.set_option("lod_walk", 0)
+
+
 def test_cfg3_octree_orbit_at_6m(gsx_fresh, pkg, oracle, synth):
     """cfg 3 at full size: 6 M splats -> 8.48 M octree nodes, frames of the 120-frame orbit.  The top-down level-by-level
     cut against (a) the general ancestor-walk kernels on every tested frame and (b) the host's Octree::get_indices
