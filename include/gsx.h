@@ -160,9 +160,12 @@ int gsx_get_sort_samples(gsx_ctx* ctx, double* sum_ms, uint32_t* sorts, int rese
  *   "sort_slots", "pair_slots"  workgroups the scatter kernels of the depth sort / of the binner's pair sort keep resident
  *                   (8 .. 2048; default: as many as the GPU holds, 512 on MI355X); fewer leave registers and LDS to the
  *                   kernels of the context's other streams (measured: no gain)
- *   "lod_walk"      1 = cut an octree with the general kernels (every node tests itself, then walks its ancestor chain)
- *                   even when it is laid out in BFS order, for which the default is the top-down level-by-level cut;
- *                   same result, kept for A/B measurements and as the path for trees in any other order
+ *   "lod_walk"      how an octree laid out in BFS order is cut.  0 (default): top-down in three launches (leading levels,
+ *                   everything below from per-workgroup stacks in LDS, one-launch compaction).  2: top-down with one launch
+ *                   per level and a three-launch compaction (round 2's form).  1: the general kernels (every node tests
+ *                   itself, then walks its ancestor chain), which are also the path for trees in any other order.  Same
+ *                   result under all three; 1 and 2 are kept for A/B measurements.  (1 and 2 also send HC cuts, list and
+ *                   band selections through the three-launch compaction.)
  * Unknown name -> GSX_E_INVALID. */
 int gsx_set_option(gsx_ctx* ctx, const char* name, uint64_t value);
 

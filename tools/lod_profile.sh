@@ -6,7 +6,7 @@ tag=${1:-r2}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 rm -rf gpurun_out/prof_${tag}_cfg3
 # (one stream, one frame at a time: the per-kernel durations are then the kernels' own)
-export GSX_OPTS="async_sort=0 frames_in_flight=1"
+export GSX_OPTS="async_sort=0 frames_in_flight=1 $GSX_LOD_EXTRA_OPTS"
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${tag}_cfg3 -o cfg3 -- python3 tools/configs_table.py cfg3 > gpurun_out/${tag}_cfg3.json 2> gpurun_out/${tag}_cfg3.err
 unset GSX_OPTS
 python tools/kstats.py gpurun_out/prof_${tag}_cfg3 > gpurun_out/${tag}_cfg3_kernel_stats.txt
