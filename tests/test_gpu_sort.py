@@ -336,6 +336,38 @@ def test_gridhc_depth_cut_through_select_list(gsx, oracle):
         assert np.array_equal(gsx.sort(cam), oracle.sort_contract(g["g_splats"], cam, np.sort(ref_cut)))
 
 
+def test_gridhc_metric_cut_at_250k(gsx_fresh, pkg, oracle, synth):
+    """cfg 3's other LOD structure beyond fixture size: GridHC (20^3 cells, GridHC.cpp:10-74) over 250 K clustered splats,
+    built by the host builder (bit-identical to the reference's, tests/test_host.py), cut on the device by the error metric
+    (HC.cpp:100-132 per cell root) along the orbit, against the CPU oracle's cut of every cell; the permutation of one cut
+    against the sort contract."""
+    import importlib
+    lod = importlib.import_module("gaussian_splatting_amd.lod")
+    gsx = gsx_fresh
+    splats = oracle.raw_to_splat(synth.clustered_cloud(250_000, seed=9))
+    t = lod.build_gridhc(splats)
+    assert t.n > 400_000 and len(t.roots) > 1000
+    t.upload(gsx)
+    crs = t.cell_root_start
+    pos = np.ascontiguousarray(t.splats[:, 12:15])
+    err = t.error * t.weight
+    thrs = [float(np.quantile(err[err > 0], q)) / 25.0 for q in (0.5, 0.9, 0.99)]
+    sizes = []
+    for f in (0, 40, 80):
+        world, _ = oracle.orbit_world(5.0, (0.0, 1.0, 0.0), 2.0 * np.pi / 120.0, f)
+        cam = np.ascontiguousarray(world[12:15])
+        for thr in thrs:
+            want = np.sort(np.concatenate([oracle.hc_cut_metric(np.ascontiguousarray(t.roots[crs[c]:crs[c + 1]]), t.child2, t.error, t.weight, pos, cam, thr)
+                                           for c in range(len(crs) - 1) if crs[c + 1] > crs[c]]))
+            assert gsx.select_hc(cam, thr) == len(want)
+            assert np.array_equal(gsx.selection(), want)
+            sizes.append(len(want))
+    assert min(sizes) < 0.8 * max(sizes) and min(sizes) >= len(t.roots)     # the thresholds cut at different depths
+    perm = gsx.sort(cam)
+    assert np.array_equal(perm, oracle.sort_contract(t.splats, cam, want))
+    t.close()
+
+
 def test_error_flags_are_reported_once(gsx_fresh, pkg, oracle, synth):
     """A bad selection list (id >= n) or a non-finite position is reported by the call that meets it and by no later one:
     the device error words are cleared once read, so the context keeps working (they used to be sticky)."""

@@ -121,6 +121,15 @@ __global__ __launch_bounds__(NT) void k_cp_exp(const uint8_t* __restrict__ flags
     if (tid == 0 && ts) { uint64_t* o = ts + blockIdx.x * 5u; o[0] = t0; o[1] = t1; o[2] = t2; o[3] = t3; o[4] = t4; }
 }
 
+// the walk's stores: one byte per emitted node, ids in the order a walk visits them (shuffled in blocks of 8)
+template <int MODE>
+__global__ __launch_bounds__(256) void k_stamp(const uint32_t* __restrict__ ids, uint32_t m, uint8_t stamp, uint8_t* __restrict__ flags) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= m) return;
+    if (MODE == 1) __builtin_nontemporal_store(stamp, flags + ids[i]);
+    else flags[ids[i]] = stamp;
+}
+
 int main(int argc, char** argv) {
     const uint32_t n = argc > 1 ? (uint32_t)atoll(argv[1]) : 8484260u;
     const int reps = argc > 2 ? atoi(argv[2]) : 30;
@@ -195,6 +204,30 @@ int main(int argc, char** argv) {
                    (ts[b * 5 + 2] - ts[b * 5 + 1]) * 0.01, (ts[b * 5 + 3] - ts[b * 5 + 2]) * 0.01, (ts[b * 5 + 4] - ts[b * 5 + 3]) * 0.01);
         printf("\n");
     };
+    {   // the shipped launch behind scattered stamp stores (what the frame loop does): events around the compaction only
+        std::vector<uint32_t> order(ref);
+        for (size_t b = 0; b + 8 <= order.size(); b += 8) { const size_t o = (rng() % (order.size() / 8)) * 8; for (int k = 0; k < 8; ++k) std::swap(order[b + k], order[o + k]); }
+        uint32_t* d_ids; CK(hipMalloc(&d_ids, order.size() * 4)); CK(hipMemcpy(d_ids, order.data(), order.size() * 4, hipMemcpyHostToDevice));
+        const uint32_t upt = (units + GSX_CP1_NT * GSX_CP1_MAXG - 1) / (GSX_CP1_NT * GSX_CP1_MAXG), g = (units + GSX_CP1_NT * upt - 1) / (GSX_CP1_NT * upt);
+        const uint32_t m = (uint32_t)order.size();
+        for (int mode = 0; mode < 2; ++mode) {
+            float sum = 0, sum_st = 0;
+            for (int i = 0; i < reps + 3; ++i) {
+                hipEvent_t a, b, c0; CK(hipEventCreate(&a)); CK(hipEventCreate(&b)); CK(hipEventCreate(&c0));
+                CK(hipEventRecord(c0, 0));
+                if (mode) hipLaunchKernelGGL(k_stamp<1>, dim3((m + 255) / 256), dim3(256), 0, 0, d_ids, m, (uint8_t)7, d_f);
+                else hipLaunchKernelGGL(k_stamp<0>, dim3((m + 255) / 256), dim3(256), 0, 0, d_ids, m, (uint8_t)7, d_f);
+                CK(hipEventRecord(a, 0));
+                hipLaunchKernelGGL(k_compact_onepass, dim3(g), dim3(GSX_CP1_NT), 0, 0, d_f, n, 7u, upt, d_agg, ++seq, d_out, d_m, (uint32_t*)nullptr, d_fl);
+                CK(hipEventRecord(b, 0)); CK(hipEventSynchronize(b));
+                float ms, ms2; CK(hipEventElapsedTime(&ms, a, b)); CK(hipEventElapsedTime(&ms2, c0, a));
+                if (i >= 3) { sum += ms; sum_st += ms2; }
+                CK(hipEventDestroy(a)); CK(hipEventDestroy(b)); CK(hipEventDestroy(c0));
+            }
+            printf("behind %zu scattered byte stores (%s): stores %.2f us, compaction %.2f us  %s\n", order.size(), mode ? "nontemporal" : "plain", sum_st * 1000.f / reps,
+                   sum * 1000.f / reps, check("behind stores") ? "ok" : "WRONG");
+        }
+    }
     for (uint32_t upt : {3u, 2u, 1u}) {
         exp(k_cp_exp<512, 0, true>, 512, upt, "consecutive units, staged,");
         exp(k_cp_exp<512, 1, true>, 512, upt, "tile-coalesced, staged,   ");
