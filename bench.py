@@ -29,10 +29,12 @@ ranks.  Beside the headline (a new pose every step) the line carries `ms_per_ste
 schedule and exact rank caps) and `ms_per_step_no_history` (one pose, every iteration pre-queued, no caps) at N = 1.
 The depth sort of frame k+1 runs on a stream of its own beside the binning / rasterizing of frame k (include/gsx.h, option
 "async_sort").  `roofline` describes the two HBM passes of the depth sort (k2_partition and k2_local; the radix scatter
-kernel k_radix_scatter<u32> where the library runs its LSD form): inside the timed region every 4th (runs under 40 steps)
-or 8th sort is a SAMPLED one -- alternately every such launch of the sort bracketed by its own pair of HIP events, and keys
-+ sort bracketed as a whole -- on the stream it runs on, and that sort runs on the main stream, not beside the rasterizer,
-so that a bracket measures the kernel itself rather than its share of a GPU it splits with another kernel.  `roofline_raster`, the per-stage breakdown and the
+kernel k_radix_scatter<u32> where the library runs its LSD form): inside the timed region every 5th (runs under 40 steps)
+or steps/4-th (8..16) sort is a SAMPLED one -- two of three with every such launch of the sort bracketed by its own pair of HIP
+events, the third with keys + sort bracketed as a whole -- on the stream it runs on, and that sort runs on the main stream, not beside the rasterizer,
+so that a bracket measures the kernel itself rather than its share of a GPU it splits with another kernel.  A sampled sort
+costs the two-frame pipeline about one frame time: `ms_per_step_unsampled` repeats the headline's loop at profiling level 0.
+`roofline_raster`, the per-stage breakdown and the
 rasterizer's shade / blend counts come from a few extra frames after the timed region with every stage bracketed.
 `cpu_baseline` times the CPU port of the reference's sortSplats on rank 0.
 """
@@ -277,8 +279,14 @@ def main():
     for o in a.opt:
         k, v = o.split("=")
         g.set_option(k, int(v))
-    g.set_option("sample_every", int(os.environ.get("GSX_BENCH_SAMPLE_EVERY", 4 if a.steps < 40 else 8)))     # (a short run still collects >= 6 launches and 2 whole sorts)
-    g.set_profiling(2)          # sampled sorts: alternately every HBM pass of the sort, and keys + sort as a whole, carry HIP events
+    # Sampled sorts (each one drains the two-frame pipeline, about one frame time): two of three bracket the sort's launches one
+    # by one, the third keys + sort as a whole; every 5th sort in a short run (20 steps: sorts 0, 5, 10, 15 = 6 launches and one
+    # whole sort), every steps/4-th (8..16) in longer ones.  Set again behind the warm-up so that the timed region's first sort
+    # is a sampled one (the pipeline is empty there anyway).
+    sample_every = int(os.environ.get("GSX_BENCH_SAMPLE_EVERY", 5 if a.steps < 40 else min(16, max(8, a.steps // 4))))
+    g.set_option("sample_whole_every", 3)
+    g.set_option("sample_every", sample_every)
+    g.set_profiling(2)          # sampled sorts: every HBM pass of the sort (two of three), or keys + sort as a whole (the third), carry HIP events
     u_mine = pkg.make_uniforms(my_view[1], my_view[0])
     fb_bytes = W * H * 4
     bands = mg.shard_bands(H, max(world, 1))
@@ -456,6 +464,7 @@ def main():
     gc.freeze()
     g.scatter_samples(reset=True)
     g.sort_samples(reset=True)
+    g.set_option("sample_every", sample_every)           # (restarts the count: the first timed sort is sampled)
     # Frames are queued back to back (the next frame's sort is queued behind the running frame; gsx_render waits for the
     # previous frame only to check whether it needs more iterations).  Nothing is read back inside the loop: the sampled
     # launches sit in the library's event ring and are collected after the closing fence.
@@ -541,7 +550,30 @@ def main():
                 step(my_view[2], u_mine)
             g.sync()
             extras["ms_per_step_no_history"] = (time.perf_counter() - t1) / K2 * 1e3
+            # what the instrumentation costs: the same two figures with no sort sampled (a sampled sort waits for both frame slots
+            # to drain so that its events bracket the sort alone, then the pipeline fills again)
+            g.set_profiling(0)
+            for i in range(3):
+                step(my_view[2], u_mine)
+            g.sync()
+            t1 = time.perf_counter()
+            for i in range(K2):
+                step(my_view[2], u_mine)
+            g.sync()
+            extras["ms_per_step_no_history_unsampled"] = (time.perf_counter() - t1) / K2 * 1e3
             g.set_option("no_history", 0)
+            for i in range(3):
+                step()
+            g.sync()
+            t1 = time.perf_counter()
+            for i in range(a.steps):
+                step()
+            drain()
+            g.sync()
+            extras["ms_per_step_unsampled"] = (time.perf_counter() - t1) / max(a.steps, 1) * 1e3
+            extras["unsampled_note"] = ("the headline's workload (a new pose every step, continuing along the orbit) and the no-history figure with "
+                                        "profiling level 0: no sort of the loop carries events; `value` keeps the instrumented time")
+            g.set_profiling(2)
         # stage breakdown on a few extra frames with every stage bracketed (outside the timed region)
         g.set_profiling(1)
         for i in range(n_prof + 1):
@@ -611,7 +643,7 @@ def main():
                          "per_pass_bytes": [launch_bytes[p] for p in sorted(per_pass)],
                          "launches_per_step": n_pass, "launches_timed": int(launches),
                          "algorithmic_bytes_per_launch": sum_bytes / launches if launches else None,
-                         "note": "HIP events inside the timed region: every other sampled sort (one sort in 4 or 8 is sampled) brackets each of these launches; the sampled sorts run "
+                         "note": "HIP events inside the timed region: two of three sampled sorts (one sort in 5, or in steps/4 = 8..16, is sampled) bracket each of these launches; the sampled sorts run "
                                  "on the main stream, un-overlapped (the others run beside the previous frame's rasterizer, where the same launch takes about twice as long: "
                                  "DESIGN.md 4.6); " + ("partition: 4 B key in + 8 B pair out, bucket sort (its two size classes + the gated overflow kernel as one bracket): 8 B in + 4 B out"
                                                        if form == 2 else "pass 0 priced at 12 B/key, passes >= 1 at 16 B/key")},
@@ -632,7 +664,7 @@ def main():
         if sort_n_timed:
             out["sort_only_ms"] = sort_ms_timed
             out["sort_only_samples"] = sort_n_timed
-            out["sort_only_note"] = "keys + sort bracketed as a whole by HIP events in every other sampled sort INSIDE the timed region (a sampled sort: on the main stream, not overlapped)"
+            out["sort_only_note"] = "keys + sort bracketed as a whole by HIP events in every third sampled sort INSIDE the timed region (a sampled sort: on the main stream, not overlapped)"
             out["sort_only_splats_per_s"] = n / (sort_ms_timed * 1e-3)
             out["sort_only_bytes_per_splat"] = sort_bytes
             out["sort_only_hbm_frac"] = sort_bytes * n / (sort_ms_timed * 1e-3) / 1e9 / HBM_PEAK_GBS

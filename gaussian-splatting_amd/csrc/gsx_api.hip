@@ -251,6 +251,10 @@ int gsx_set_option(gsx_ctx* c, const char* name, uint64_t value) {
         int rc = set_device(c);
         if (rc || (rc = gsx_frame_finish(c))) return rc;
         (name[0] == 's' ? c->sort_slots : c->pair_slots) = static_cast<uint32_t>(value);
+    } else if (!std::strcmp(name, "sample_whole_every")) {
+        if (value < 2 || value > 16) { c->err = "sample_whole_every must be 2..16"; return GSX_E_INVALID; }
+        c->opt_sample_whole_every = static_cast<uint32_t>(value);
+        c->prof_frame = 0;
     } else if (!std::strcmp(name, "sample_every")) {
         if (value > 1024) { c->err = "sample_every above 1024"; return GSX_E_INVALID; }
         c->opt_sample_every = value ? static_cast<uint32_t>(value) : GSX_SAMPLE_EVERY;

@@ -317,6 +317,7 @@ struct gsx_ctx : GsxFrameSlot {
     hipEvent_t ev_perm[GSX_PERM_RING] = {};   // end of the sort that filled ring slot b (recorded with sort_ahead)
     bool perm_rec[GSX_PERM_RING] = {};
     uint64_t opt_frames_in_flight = 2;
+    uint32_t opt_sample_whole_every = 2;            // ... and every how many SAMPLES one brackets keys + sort as a whole instead of its launches
     uint32_t opt_sample_every = GSX_SAMPLE_EVERY;   // profiling level 2: every how many sorts one is a sampled (synchronous) one
     bool sort_join_pending = false;      // a sort was queued on sort_stream and the main stream has not waited for it yet
     bool main_dirty = true;              // the main stream holds work the next sort must see (selection, upload): record ev_pre

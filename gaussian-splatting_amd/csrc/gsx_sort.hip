@@ -309,7 +309,7 @@ static int launch_sort_in(gsx_ctx* c, const GsxSortBuffers& sb, hipStream_t st) 
     const bool gated = top_bits != 0 && !p2.ok;      // (the two-pass form orders all 31 key bits itself: its buckets widen towards the camera)
     if (gated) GSX_HIP(c, hipMemsetAsync(&c->flags->wide_m, 0, sizeof(uint32_t), st));
     const int n_stage = p2.ok ? 2 : plan.n_passes;    // launches a level-2 sample can bracket: radix passes, or partition + bucket sort
-    // Profiling level 2: every opt_sample_every-th sort is a SAMPLED one, alternately (a) every scatter launch of the radix
+    // Profiling level 2: every opt_sample_every-th sort is a SAMPLED one, in turn (option sample_whole_every, default alternately) (a) every scatter launch of the radix
     // passes -- or the partition and the bucket-sort launches of the two-pass form -- each bracketed by its own pair of events
     // from the ring, and (b) keys + sort as a whole (slot GSX_SAMPLE_WHOLE), from before the key kernel to behind the last
     // pass.  A sampled sort runs on the main stream (gsx_launch_sort), i.e. NOT beside the previous frame's rasterizer, so
@@ -327,7 +327,7 @@ static int launch_sort_in(gsx_ctx* c, const GsxSortBuffers& sb, hipStream_t st) 
         fprintf(stderr, "[gsx] %.1f sampled sort %llu: two-pass %d nd %u ncols %u key_lo %#x key_span %#x\n", gsx_dbg_now(), (unsigned long long)c->prof_frame, (int)p2.ok, p2.nd, p2.ncols, key_lo, key_span);
     if (sb.with_events) {
         if (c->prof_level == 2 && n_stage > 0 && c->prof_frame % c->opt_sample_every == 0u) {
-            if ((c->prof_frame / c->opt_sample_every) % 2u == 1u) {
+            if ((c->prof_frame / c->opt_sample_every) % c->opt_sample_whole_every == c->opt_sample_whole_every - 1u) {
                 sampled_pass = GSX_SAMPLE_WHOLE;
                 take_slot(GSX_SAMPLE_WHOLE);
             } else {

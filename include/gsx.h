@@ -156,7 +156,11 @@ int gsx_get_sort_samples(gsx_ctx* ctx, double* sum_ms, uint32_t* sorts, int rese
  *                   rank caps; the radius needed follows from how far the scene moved on screen since the slot's last frame
  *   "sample_every"  profiling level 2: every how many sorts one is a sampled one (default 8; a sampled sort runs on the main
  *                   stream behind every queued frame, and what is queued on the other streams while it runs starts behind it,
- *                   so that its events time the kernels themselves - which costs the pipeline one bubble per sample)
+ *                   so that its events time the kernels themselves - which costs the pipeline one bubble per sample,
+ *                   about one frame time: bench.py reports its frame time with and without them)
+ *   "sample_whole_every"  profiling level 2: every how many SAMPLED sorts one brackets keys + sort as a whole instead of
+ *                   its launches one by one (2..16, default 2 = alternately).  Setting either option restarts the count: the
+ *                   next sort is a sampled one.
  *   "sort_slots", "pair_slots"  workgroups the scatter kernels of the depth sort / of the binner's pair sort keep resident
  *                   (8 .. 2048; default: as many as the GPU holds, 512 on MI355X); fewer leave registers and LDS to the
  *                   kernels of the context's other streams (measured: no gain)
