@@ -30,8 +30,8 @@ schedule and exact rank caps) and `ms_per_step_no_history` (one pose, every iter
 The depth sort of frame k+1 runs on a stream of its own beside the binning / rasterizing of frame k (include/gsx.h, option
 "async_sort").  `roofline` describes the two HBM passes of the depth sort (k2_partition and k2_local; the radix scatter
 kernel k_radix_scatter<u32> where the library runs its LSD form): inside the timed region every 5th (runs under 40 steps)
-or steps/4-th (8..16) sort is a SAMPLED one -- two of three with every such launch of the sort bracketed by its own pair of HIP
-events, the third with keys + sort bracketed as a whole -- on the stream it runs on, and that sort runs on the main stream, not beside the rasterizer,
+or steps/4-th (8..16) sort is a SAMPLED one -- two of three (three of four in the short runs) with every such launch of the sort
+bracketed by its own pair of HIP events, the next with keys + sort bracketed as a whole -- on the stream it runs on, and that sort runs on the main stream, not beside the rasterizer,
 so that a bracket measures the kernel itself rather than its share of a GPU it splits with another kernel.  A sampled sort
 costs the two-frame pipeline about one frame time: `ms_per_step_unsampled` repeats the headline's loop at profiling level 0.
 `roofline_raster`, the per-stage breakdown and the
@@ -280,11 +280,11 @@ def main():
         k, v = o.split("=")
         g.set_option(k, int(v))
     # Sampled sorts (each one drains the two-frame pipeline, about one frame time): two of three bracket the sort's launches one
-    # by one, the third keys + sort as a whole; every 5th sort in a short run (20 steps: sorts 0, 5, 10, 15 = 6 launches and one
-    # whole sort), every steps/4-th (8..16) in longer ones.  Set again behind the warm-up so that the timed region's first sort
+    # by one, the third keys + sort as a whole, every steps/4-th sort (8..16); in a short run every 5th sort, three of four by
+    # launches (20 steps: sorts 0, 5, 10 = 6 launches, sort 15 as a whole).  Set again behind the warm-up so that the timed region's first sort
     # is a sampled one (the pipeline is empty there anyway).
     sample_every = int(os.environ.get("GSX_BENCH_SAMPLE_EVERY", 5 if a.steps < 40 else min(16, max(8, a.steps // 4))))
-    g.set_option("sample_whole_every", 3)
+    g.set_option("sample_whole_every", int(os.environ.get("GSX_BENCH_SAMPLE_WHOLE_EVERY", 4 if a.steps < 40 else 3)))
     g.set_option("sample_every", sample_every)
     g.set_profiling(2)          # sampled sorts: every HBM pass of the sort (two of three), or keys + sort as a whole (the third), carry HIP events
     u_mine = pkg.make_uniforms(my_view[1], my_view[0])
