@@ -72,7 +72,8 @@ int alloc_scene(gsx_ctx* c, uint64_t n) {
     if ((rc = dev_alloc(c, &c->s2_pairs, n)) || (rc = dev_alloc(c, &c->s2_scratch, n))) return rc;
     c->s2_ws_bytes = gsx_sort2_ws_bytes(n);
     if ((rc = dev_alloc(c, &c->s2_ws, c->s2_ws_bytes))) return rc;
-    c->s2_backoff = c->s2_backoff_len = 0;
+    for (int r = 0; r < 24; ++r) c->s2_backoff[r] = c->s2_backoff_len[r] = 0;
+    c->s2_mid_left = 0;
     // LOD / list-selection scratch (flags padded for 16-byte vector loads)
     const uint64_t fl = (n + 15) / 16 * 16 + 16;
     if ((rc = dev_alloc(c, &c->lod_stop, fl)) || (rc = dev_alloc(c, &c->lod_emit, fl))) return rc;
@@ -262,7 +263,7 @@ int gsx_set_option(gsx_ctx* c, const char* name, uint64_t value) {
     } else if (!std::strcmp(name, "sort_algo")) {
         if (value > 2) { c->err = "sort_algo must be 0 (automatic), 1 (LSD passes) or 2 (two-pass whenever its plan allows)"; return GSX_E_INVALID; }
         c->opt_sort_algo = value;
-        c->s2_backoff = c->s2_backoff_len = 0;
+        for (int r = 0; r < 24; ++r) c->s2_backoff[r] = c->s2_backoff_len[r] = 0;
     } else if (!std::strcmp(name, "async_sort")) {
         c->opt_async_sort = value ? 1 : 0;
     } else if (!std::strcmp(name, "sort_ahead")) {

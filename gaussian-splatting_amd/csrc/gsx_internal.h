@@ -256,7 +256,13 @@ struct gsx_ctx : GsxFrameSlot {
     hipEvent_t ev_s2_stats = nullptr;
     bool s2_stats_rec = false;
     uint32_t s2_stats_tick = 0;
-    uint32_t s2_backoff = 0, s2_backoff_len = 0;   // sorts left on the LSD passes after a sort that sent many keys through k2_big / length of the next pause
+    // sorts left on the LSD passes after a sort that sent many keys through k2_big / length of the next such stretch - kept per
+    // bucket width r0 of the plan: a pose whose key range forces coarse buckets says nothing about the poses that get fine ones
+    // (cfg 4 deals 64 different views in turn)
+    uint32_t s2_backoff[24] = {}, s2_backoff_len[24] = {};
+    uint32_t s2_stats_r0 = 0;          // r0 of the sort whose statistics are on their way
+    uint32_t s2_mid_left = 0;          // > 0: the sorts launch k2_local's third instance (buckets of 9217 .. 16384 pairs in LDS); re-armed by the statistics
+    bool s2_stats_mid = false;         // whether the sort whose statistics are on their way ran with it
     uint32_t s2_hint_scale = 1;
     uint32_t s2_m_hint = 0, s2_hint_cap = 0;   // selection size seen by a recent two-pass sort (x 1.5) and the capacity it was seen under: sizes the bucket count
     uint64_t opt_sort_algo = 0;                    // 0 automatic, 1 LSD passes only, 2 two-pass whenever its plan allows (any size)

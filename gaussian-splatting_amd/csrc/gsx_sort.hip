@@ -288,15 +288,22 @@ static int launch_sort_in(gsx_ctx* c, const GsxSortBuffers& sb, hipStream_t st) 
             // overflowed although the hint was below the capacity mean the selection has grown: forget the hint
             const uint32_t seen = c->s2_stats_host->keys;
             const bool hinted = c->s2_hint_cap == cap && c->s2_m_hint != 0 && c->s2_m_hint < cap;
-            if (c->s2_stats_host->big_keys != 0 && hinted) {
+            // buckets over GSX2_CAP: the following sorts launch the third k2_local instance (up to GSX2_CAP2 in LDS); it is
+            // dropped again after ~1000 sorts that did not need it
+            if (c->s2_stats_host->max_bucket > GSX2_CAP) c->s2_mid_left = 256u;
+            else if (c->s2_mid_left) --c->s2_mid_left;
+            uint32_t big_keys = c->s2_stats_host->big_keys;      // keys of that sort no instance took in LDS ...
+            if (!c->s2_stats_mid && c->s2_stats_host->max_bucket <= GSX2_CAP2) big_keys = 0u;   // ... all of which the third instance takes from now on
+            if (big_keys != 0 && hinted) {
                 c->s2_m_hint = 0;
                 if (c->s2_hint_scale < 64u) c->s2_hint_scale *= 2u;         // (or the scene is denser than its size says: size the buckets for more)
             } else {
-                if (static_cast<uint64_t>(c->s2_stats_host->big_keys) * 64ull > cap) {
-                    c->s2_backoff_len = c->s2_backoff_len ? (c->s2_backoff_len < 512u ? c->s2_backoff_len * 2u : 1024u) : 16u;
-                    c->s2_backoff = c->s2_backoff_len;
-                } else if (c->s2_stats_host->big_keys == 0) {
-                    c->s2_backoff_len = 0;
+                if (static_cast<uint64_t>(big_keys) * 64ull > cap) {
+                    uint32_t& len = c->s2_backoff_len[c->s2_stats_r0];
+                    len = len ? (len < 512u ? len * 2u : 1024u) : 16u;
+                    c->s2_backoff[c->s2_stats_r0] = len;
+                } else if (big_keys == 0) {
+                    c->s2_backoff_len[c->s2_stats_r0] = 0;
                 }
                 const uint64_t want = (static_cast<uint64_t>(seen) + seen / 2u) * c->s2_hint_scale;   // (half as much again: cuts along an orbit vary by ~20 %)
                 c->s2_m_hint = want < cap ? static_cast<uint32_t>(want) : cap;
@@ -304,7 +311,8 @@ static int launch_sort_in(gsx_ctx* c, const GsxSortBuffers& sb, hipStream_t st) 
             }
         }
         p2 = gsx2_plan(key_span, cap, c->n, 0, c->opt_sort_algo == 2, c->s2_hint_cap == cap ? c->s2_m_hint : 0u);
-        if (p2.ok && c->opt_sort_algo == 0 && c->s2_backoff) { --c->s2_backoff; p2.ok = false; }
+        if (p2.ok && c->opt_sort_algo == 0 && c->s2_backoff[p2.map.r0]) { --c->s2_backoff[p2.map.r0]; p2.ok = false; }
+        if (g_dbg_sort2) fprintf(stderr, "[gsx] plan: two-pass %d r0 %u nd %u key_span %#x back-off left %u mid %u\n", (int)p2.ok, p2.map.r0, p2.nd, key_span, p2.map.r0 < 24u ? c->s2_backoff[p2.map.r0] : 0u, c->s2_mid_left);
     }
     const bool gated = top_bits != 0 && !p2.ok;      // (the two-pass form orders all 31 key bits itself: its buckets widen towards the camera)
     if (gated) GSX_HIP(c, hipMemsetAsync(&c->flags->wide_m, 0, sizeof(uint32_t), st));
@@ -343,6 +351,8 @@ static int launch_sort_in(gsx_ctx* c, const GsxSortBuffers& sb, hipStream_t st) 
     uint32_t cur = 0;
     uint32_t* result = sb.result;
     bool want_stats = false;
+    const bool mid = p2.ok && c->s2_mid_left > 0u;
+    const uint32_t cap_lds = mid ? GSX2_CAP2 : GSX2_CAP;
     if (p2.ok) {
         const Gsx2Workspace w = gsx2_ws_carve(c->s2_ws, c->sort_cap);
         if (c->sel_iota)
@@ -358,17 +368,19 @@ static int launch_sort_in(gsx_ctx* c, const GsxSortBuffers& sb, hipStream_t st) 
         if (e0) GSX_HIP(c, hipEventRecord(e0, st));
         if (c->sel_iota)
             hipLaunchKernelGGL(k2_partition<true>, dim3(p2.ncols), dim3(GSX2_PNT), 0, st, sb.keys[0], nullptr, c->m_dev, p2.map, p2.nd,
-                               w.cnt, w.pre, w.totals, w.base, c->s2_pairs, w.stats, c->flags);
+                               w.cnt, w.pre, w.totals, w.base, c->s2_pairs, w.stats, c->flags, cap_lds);
         else
             hipLaunchKernelGGL(k2_partition<false>, dim3(p2.ncols), dim3(GSX2_PNT), 0, st, sb.keys[0], c->sel_idx, c->m_dev, p2.map,
-                               p2.nd, w.cnt, w.pre, w.totals, w.base, c->s2_pairs, w.stats, c->flags);
+                               p2.nd, w.cnt, w.pre, w.totals, w.base, c->s2_pairs, w.stats, c->flags, cap_lds);
         if (e1) GSX_HIP(c, hipEventRecord(e1, st));
         e0 = profiling ? c->ev[EV_X0 + 2] : samp_a[1];
         e1 = profiling ? c->ev[EV_X0 + 3] : samp_b[1];
         if (e0) GSX_HIP(c, hipEventRecord(e0, st));
         // two instances by bucket size; the larger one also sorts what does not fit LDS (through the scratch twin of the pairs)
-        hipLaunchKernelGGL((k2_local<GSX2_IPT>), dim3(p2.nd), dim3(GSX2_NT), 0, st, c->s2_pairs, c->s2_scratch, w.base, p2.nd, p2.map, p2.idx_bits, result);
-        hipLaunchKernelGGL((k2_local<8>), dim3(p2.nd), dim3(GSX2_NT), 0, st, c->s2_pairs, c->s2_scratch, w.base, p2.nd, p2.map, p2.idx_bits, result);
+        hipLaunchKernelGGL((k2_local<GSX2_IPT>), dim3(p2.nd), dim3(GSX2_NT), 0, st, c->s2_pairs, c->s2_scratch, w.base, p2.nd, p2.map, p2.idx_bits, result, cap_lds);
+        if (mid)   // (only while recent sorts had buckets of 9217 .. 16384 pairs: a launch that finds nothing to do costs 5 us)
+            hipLaunchKernelGGL((k2_local<GSX2_IPT2>), dim3(p2.nd), dim3(GSX2_NT), 0, st, c->s2_pairs, c->s2_scratch, w.base, p2.nd, p2.map, p2.idx_bits, result, cap_lds);
+        hipLaunchKernelGGL((k2_local<8>), dim3(p2.nd), dim3(GSX2_NT), 0, st, c->s2_pairs, c->s2_scratch, w.base, p2.nd, p2.map, p2.idx_bits, result, cap_lds);
         if (e1) GSX_HIP(c, hipEventRecord(e1, st));
         want_stats = true;
     } else {
@@ -410,6 +422,8 @@ static int launch_sort_in(gsx_ctx* c, const GsxSortBuffers& sb, hipStream_t st) 
         GSX_HIP(c, hipMemcpyAsync(c->s2_stats_host, w.stats, sizeof(Gsx2Stats), hipMemcpyDeviceToHost, st));
         GSX_HIP(c, hipEventRecord(c->ev_s2_stats, st));
         c->s2_stats_rec = true;
+        c->s2_stats_mid = mid;
+        c->s2_stats_r0 = p2.map.r0;
     }
     if (profiling) GSX_HIP(c, hipEventRecord(c->ev[EV_SORT1], st));
     GSX_HIP(c, hipGetLastError());
@@ -417,7 +431,7 @@ static int launch_sort_in(gsx_ctx* c, const GsxSortBuffers& sb, hipStream_t st) 
         c->sort_passes = static_cast<uint32_t>(n_stage) + (gated ? 1u : 0u);   // (the gated pass counts as launched)
         c->sort_gated = gated;
         c->sort_two_pass = p2.ok;
-        c->sort_launches = p2.ok ? 5u : 3u * static_cast<uint32_t>(plan.n_passes) - 1u;   // (pass 0's count is fused into the key kernel)
+        c->sort_launches = p2.ok ? (mid ? 6u : 5u) : 3u * static_cast<uint32_t>(plan.n_passes) - 1u;   // (pass 0's count is fused into the key kernel)
     }
     return GSX_OK;
 }

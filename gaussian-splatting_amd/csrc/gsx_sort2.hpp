@@ -35,10 +35,12 @@
 #define GSX2_KPT (GSX2_COLMAX / GSX2_PNT)
 #define GSX2_CAP 9216                    // pairs of the largest bucket k2_local sorts in LDS
 #define GSX2_IPT (GSX2_CAP / GSX2_NT)
+#define GSX2_IPT2 32                     // the third instance of k2_local, launched only for scenes that need it ...
+#define GSX2_CAP2 (GSX2_IPT2 * GSX2_NT)  // ... sorts buckets of up to 16384 pairs in LDS (80 KB: one or two workgroups per CU)
 #define GSX2_MAX_Q 13                    // bits of k2_local's bins at most (2^13 packed 16-bit bins = 16 KB)
 
 struct Gsx2Stats {
-    uint32_t big_buckets;    // buckets larger than GSX2_CAP in the latest sort (k2_partition, block 0)
+    uint32_t big_buckets;    // buckets larger than what that sort's k2_local instances took in LDS (GSX2_CAP, or GSX2_CAP2 with the third instance)
     uint32_t big_keys;       // keys in them
     uint32_t max_bucket;
     uint32_t keys;           // selection size of that sort (a cut's size is known only on the device: the next plan sizes its buckets by it)
@@ -176,7 +178,8 @@ __global__ __launch_bounds__(GSX2_PNT) void k2_partition(const uint32_t* __restr
                                                          const uint32_t* __restrict__ m_ptr, Gsx2Map mp, uint32_t nd,
                                                          const uint16_t* __restrict__ cnt, const uint32_t* __restrict__ pre,
                                                          const uint32_t* __restrict__ totals, uint32_t* __restrict__ base_out,
-                                                         uint2* __restrict__ pairs, Gsx2Stats* __restrict__ stats, GsxDevFlags* __restrict__ flags) {
+                                                         uint2* __restrict__ pairs, Gsx2Stats* __restrict__ stats, GsxDevFlags* __restrict__ flags,
+                                                         uint32_t cap_lds /* largest bucket this sort's k2_local launches take in LDS */) {
     __shared__ uint2 s_pair[GSX2_COLMAX];
     __shared__ uint32_t s_cur[GSX2_MAX_D / 2];     // packed 16-bit slot cursors (start of the bucket inside the column, then running)
     __shared__ uint32_t s_adj[GSX2_MAX_D];         // output index of slot p of bucket d = s_adj[d] + p
@@ -232,7 +235,7 @@ __global__ __launch_bounds__(GSX2_PNT) void k2_partition(const uint32_t* __restr
                 if (col == 0) {
                     base_out[d] = acc;
                     if (d + 1 == nd) base_out[nd] = acc + tot[j + h];
-                    if (tot[j + h] > GSX2_CAP) { ++nbig; kbig += tot[j + h]; }
+                    if (tot[j + h] > cap_lds) { ++nbig; kbig += tot[j + h]; }
                     mx = tot[j + h] > mx ? tot[j + h] : mx;
                 }
             }
@@ -274,16 +277,20 @@ __global__ __launch_bounds__(GSX2_PNT) void k2_partition(const uint32_t* __restr
 // in LDS -- a larger bucket, or a coarse bucket near the camera whose key bits do not fit the word -- through
 // gsx2_big_bucket (defined below).  (A third instance for 8192 .. 12288 pairs at 64 KB cost every sort a launch that
 // found nothing to do: 5 us.  9216 is what three workgroups per CU leave room for; the bench orbit's largest bucket is 8819.)
+// That third instance exists all the same, IPT = GSX2_IPT2 = 32 (9217 .. 16384 pairs, 80 KB), and is launched only while the
+// statistics of recent sorts show buckets over GSX2_CAP (the host passes cap_lds = GSX2_CAP2 to all instances then): at
+// 20 M clustered splats and 5 120 buckets, 559 buckets hold 9 .. 12 K pairs, which one workgroup each sorted through
+// global memory in 291 us (tools/sort2bench.hip).
 __device__ __forceinline__ void gsx2_big_bucket(uint2* pairs, uint2* scratch, uint32_t b0, uint32_t size, uint32_t r, uint32_t idx_bits,
                                                 uint32_t* result, uint32_t* lds);
 
 template <int IPT>
-__global__ __launch_bounds__(GSX2_NT) __attribute__((amdgpu_waves_per_eu(IPT == 8 ? 8 : 6, IPT == 8 ? 8 : 6)))
+__global__ __launch_bounds__(GSX2_NT) __attribute__((amdgpu_waves_per_eu(IPT == 8 ? 8 : (IPT == GSX2_IPT ? 6 : 2), IPT == 8 ? 8 : (IPT == GSX2_IPT ? 6 : 2))))
 void k2_local(uint2* pairs, uint2* scratch, const uint32_t* __restrict__ base, uint32_t nd, Gsx2Map mp, uint32_t idx_bits,
-              uint32_t* __restrict__ result) {
-    constexpr bool REST = IPT > 8;                   // the instance that also takes what does not fit LDS
+              uint32_t* __restrict__ result, uint32_t cap_lds /* GSX2_CAP, or GSX2_CAP2 when the IPT2 instance is launched too */) {
+    constexpr bool REST = IPT == GSX2_IPT;           // the instance that also takes what does not fit LDS
     constexpr int QMAX = GSX2_MAX_Q;
-    constexpr uint32_t LO = IPT == 8 ? 0u : 8u * GSX2_NT, HI = IPT * GSX2_NT;
+    constexpr uint32_t LO = IPT == 8 ? 0u : (IPT == GSX2_IPT ? 8u * GSX2_NT : static_cast<uint32_t>(GSX2_CAP)), HI = IPT * GSX2_NT;
     __shared__ uint32_t s_bins[(1 << QMAX) / 2];    // packed 16-bit: counts, then exclusive starts
     __shared__ uint32_t s_comp[IPT * GSX2_NT];
     __shared__ uint32_t s_tmp[GSX2_NT / 64];
@@ -298,7 +305,7 @@ void k2_local(uint2* pairs, uint2* scratch, const uint32_t* __restrict__ base, u
     const uint32_t q_max = r < static_cast<uint32_t>(QMAX) ? r : static_cast<uint32_t>(QMAX);
     const uint32_t q_min = r + idx_bits > 32u ? r + idx_bits - 32u : 0u;
     const bool unpackable = size > 64u && q_min > (r < static_cast<uint32_t>(GSX2_MAX_Q) ? r : static_cast<uint32_t>(GSX2_MAX_Q));
-    if (size > GSX2_CAP || unpackable) {
+    if (size > cap_lds || unpackable) {
         if (REST) gsx2_big_bucket(pairs, scratch, b0, size, r, idx_bits, result, s_comp);
         return;
     }
@@ -563,8 +570,10 @@ static inline Gsx2Plan gsx2_plan(uint32_t key_span, uint32_t m_cap, uint64_t n_i
     while ((fine_span >> bits) != 0) ++bits;
     uint32_t t = 10;
     const uint32_t m_for_t = (m_hint && m_hint < m_cap) ? m_hint : m_cap;
-    while (t < GSX2_MAX_T - 1 && (1536ull << t) < m_for_t) ++t;  // ~1.5 K keys per bucket if they were spread evenly over the fine region
+    while (t < GSX2_MAX_T && (1536ull << t) < m_for_t) ++t;      // ~1.5 K keys per bucket if they were spread evenly over the fine region
     if (t_force) t = t_force;
+    // (13 bits only where the whole key range lies in the fine region: behind it the coarse buckets would not fit the tables)
+    if (!t_force && t == GSX2_MAX_T && key_span >= (1u << 25)) t = GSX2_MAX_T - 1;
     if (bits < t + 5) return p;                                   // narrow key range: the LSD passes are as good
     if (m_cap < (1u << 17) && !any_size) return p;                // small sorts are launch-bound either way
     if (n_ids == 0 || m_cap == 0) return p;

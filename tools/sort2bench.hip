@@ -40,6 +40,8 @@ int main(int argc, char** argv) {
     }
     if (scene == "equal") { pos[0] = make_float4(3, 3, -3, 1); pos[1] = make_float4(0, 0, 3, 1); }   // (a key range wide enough for the plan)
     const bool inside = argc > 5 && atoi(argv[5]);
+    const bool mid = argc > 6 && atoi(argv[6]);          // launch k2_local's third instance (buckets of 9217 .. 16384 pairs in LDS)
+    const uint32_t cap_lds = mid ? GSX2_CAP2 : GSX2_CAP;
     const float cx = inside ? 0.4f : 0.f, cy = inside ? -0.3f : 0.f, cz = inside ? 0.9f : 5.f;
     std::vector<uint32_t> hkey(n);
     float dmin = 1e30f, dmax = 0.f;
@@ -78,12 +80,13 @@ int main(int argc, char** argv) {
         CK(hipEventRecord(ev[1], st));
         hipLaunchKernelGGL(k2_scan, dim3(plan.nd / 16), dim3(512), 0, st, d_cnt, d_pre, d_tot, plan.nd, plan.ncols);
         CK(hipEventRecord(ev[2], st));
-        hipLaunchKernelGGL(k2_partition<true>, dim3(plan.ncols), dim3(GSX2_PNT), 0, st, d_keys, nullptr, d_m, plan.map, plan.nd, d_cnt, d_pre, d_tot, d_base, d_pairs, d_stats, d_flags);
+        hipLaunchKernelGGL(k2_partition<true>, dim3(plan.ncols), dim3(GSX2_PNT), 0, st, d_keys, nullptr, d_m, plan.map, plan.nd, d_cnt, d_pre, d_tot, d_base, d_pairs, d_stats, d_flags, cap_lds);
         CK(hipEventRecord(ev[3], st));
-        hipLaunchKernelGGL((k2_local<GSX2_IPT>), dim3(plan.nd), dim3(GSX2_NT), 0, st, d_pairs, d_scratch, d_base, plan.nd, plan.map, plan.idx_bits, d_res);
+        hipLaunchKernelGGL((k2_local<GSX2_IPT>), dim3(plan.nd), dim3(GSX2_NT), 0, st, d_pairs, d_scratch, d_base, plan.nd, plan.map, plan.idx_bits, d_res, cap_lds);
+        if (mid) hipLaunchKernelGGL((k2_local<GSX2_IPT2>), dim3(plan.nd), dim3(GSX2_NT), 0, st, d_pairs, d_scratch, d_base, plan.nd, plan.map, plan.idx_bits, d_res, cap_lds);
         CK(hipEventRecord(ev[6], st));
         CK(hipEventRecord(ev[4], st));
-        hipLaunchKernelGGL((k2_local<8>), dim3(plan.nd), dim3(GSX2_NT), 0, st, d_pairs, d_scratch, d_base, plan.nd, plan.map, plan.idx_bits, d_res);
+        hipLaunchKernelGGL((k2_local<8>), dim3(plan.nd), dim3(GSX2_NT), 0, st, d_pairs, d_scratch, d_base, plan.nd, plan.map, plan.idx_bits, d_res, cap_lds);
         CK(hipEventRecord(ev[5], st));
         CK(hipStreamSynchronize(st));
         CK(hipGetLastError());
