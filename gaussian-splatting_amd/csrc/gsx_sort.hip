@@ -311,8 +311,9 @@ static int launch_sort_in(gsx_ctx* c, const GsxSortBuffers& sb, hipStream_t st) 
             }
         }
         p2 = gsx2_plan(key_span, cap, c->n, 0, c->opt_sort_algo == 2, c->s2_hint_cap == cap ? c->s2_m_hint : 0u);
-        if (p2.ok && c->opt_sort_algo == 0 && c->s2_backoff[p2.map.r0]) { --c->s2_backoff[p2.map.r0]; p2.ok = false; }
-        if (g_dbg_sort2) fprintf(stderr, "[gsx] plan: two-pass %d r0 %u nd %u key_span %#x back-off left %u mid %u\n", (int)p2.ok, p2.map.r0, p2.nd, key_span, p2.map.r0 < 24u ? c->s2_backoff[p2.map.r0] : 0u, c->s2_mid_left);
+        const uint32_t bo = p2.map.rc == p2.map.r0 + 2u ? 23u : p2.map.r0;      // (the wide 13-bit plan keeps a memory of its own)
+        if (p2.ok && c->opt_sort_algo == 0 && c->s2_backoff[bo]) { --c->s2_backoff[bo]; p2.ok = false; }
+        if (g_dbg_sort2) fprintf(stderr, "[gsx] plan: two-pass %d r0 %u nd %u key_span %#x back-off left %u mid %u\n", (int)p2.ok, p2.map.r0, p2.nd, key_span, c->s2_backoff[bo], c->s2_mid_left);
     }
     const bool gated = top_bits != 0 && !p2.ok;      // (the two-pass form orders all 31 key bits itself: its buckets widen towards the camera)
     if (gated) GSX_HIP(c, hipMemsetAsync(&c->flags->wide_m, 0, sizeof(uint32_t), st));
@@ -423,7 +424,7 @@ static int launch_sort_in(gsx_ctx* c, const GsxSortBuffers& sb, hipStream_t st) 
         GSX_HIP(c, hipEventRecord(c->ev_s2_stats, st));
         c->s2_stats_rec = true;
         c->s2_stats_mid = mid;
-        c->s2_stats_r0 = p2.map.r0;
+        c->s2_stats_r0 = p2.map.rc == p2.map.r0 + 2u ? 23u : p2.map.r0;
     }
     if (profiling) GSX_HIP(c, hipEventRecord(c->ev[EV_SORT1], st));
     GSX_HIP(c, hipGetLastError());

@@ -53,13 +53,15 @@ struct Gsx2Stats {
 // distance only by 0 and the key range is the full 31 bits: the ~5 K buckets still sit where the splats are.
 struct Gsx2Map {
     uint32_t r0;      // low key bits inside a bucket of the fine region
-    uint32_t nf;      // 23 - r0: log2 of the fine buckets per window
-    uint32_t base;    // buckets of the fine region: 2^25 >> r0
+    uint32_t nf;      // log2 of twice the buckets of the first coarse window: 24 - rc
+    uint32_t base;    // buckets of the fine region: flen >> r0
+    uint32_t flen;    // key values of the fine region: 4 windows of 2^23 (3 for the 13-bit plan of a wide key range, which must leave table entries for the coarse windows)
+    uint32_t rc;      // low key bits inside a bucket of the first coarse window: r0 + 1 (r0 + 2 for that plan)
 };
 __host__ __device__ __forceinline__ uint32_t gsx2_bucket(uint32_t rel, const Gsx2Map mp) {
-    if (rel < (1u << 25)) return rel >> mp.r0;
-    const uint32_t e = (rel - (1u << 25)) >> 23;
-    if (e < mp.nf) return mp.base + (1u << mp.nf) - (1u << (mp.nf - e)) + ((rel & 0x7FFFFFu) >> (mp.r0 + 1u + e));
+    if (rel < mp.flen) return rel >> mp.r0;
+    const uint32_t e = (rel - mp.flen) >> 23;
+    if (e < mp.nf) return mp.base + (1u << mp.nf) - (1u << (mp.nf - e)) + ((rel & 0x7FFFFFu) >> (mp.rc + e));
     return mp.base + (1u << mp.nf) - 1u + (e - mp.nf);
 }
 // low key bits that vary inside bucket d
@@ -73,7 +75,7 @@ __host__ __device__ __forceinline__ uint32_t gsx2_bucket_bits(uint32_t d, const 
 #else
     const uint32_t lg = 31u - static_cast<uint32_t>(__builtin_clz(y));
 #endif
-    return mp.r0 + 1u + (mp.nf - 1u - lg);
+    return mp.rc + (mp.nf - 1u - lg);
 }
 
 // ---- A: keys + per-column counts of the top digit ------------------------------------------------------------
@@ -546,7 +548,7 @@ __device__ __forceinline__ void gsx2_big_bucket(uint2* pairs, uint2* scratch, ui
 // ---- host side ------------------------------------------------------------------------------------------------------
 struct Gsx2Plan {
     bool ok = false;
-    Gsx2Map map = {0, 0, 0};
+    Gsx2Map map = {0, 0, 0, 0, 0};
     uint32_t nd = 0, idx_bits = 0, ncols = 0;
 };
 
@@ -572,8 +574,9 @@ static inline Gsx2Plan gsx2_plan(uint32_t key_span, uint32_t m_cap, uint64_t n_i
     const uint32_t m_for_t = (m_hint && m_hint < m_cap) ? m_hint : m_cap;
     while (t < GSX2_MAX_T && (1536ull << t) < m_for_t) ++t;      // ~1.5 K keys per bucket if they were spread evenly over the fine region
     if (t_force) t = t_force;
-    // (13 bits only where the whole key range lies in the fine region: behind it the coarse buckets would not fit the tables)
-    if (!t_force && t == GSX2_MAX_T && key_span >= (1u << 25)) t = GSX2_MAX_T - 1;
+    // 13 bits behind a key range wider than the fine region: 8192 fine buckets would leave no table entries for the coarse
+    // windows, so that plan cuts three windows finely instead of four and starts the coarse ones a halving later (7.4 K buckets)
+    const bool wide13 = t == GSX2_MAX_T && key_span >= (1u << 25);
     if (bits < t + 5) return p;                                   // narrow key range: the LSD passes are as good
     if (m_cap < (1u << 17) && !any_size) return p;                // small sorts are launch-bound either way
     if (n_ids == 0 || m_cap == 0) return p;
@@ -582,8 +585,10 @@ static inline Gsx2Plan gsx2_plan(uint32_t key_span, uint32_t m_cap, uint64_t n_i
     p.ncols = ncols;
     p.map.r0 = bits - t;
     if (p.map.r0 > 22u) return p;
-    p.map.nf = 23u - p.map.r0;
-    p.map.base = (1u << 25) >> p.map.r0;
+    p.map.flen = wide13 ? (3u << 23) : (1u << 25);
+    p.map.rc = p.map.r0 + (wide13 ? 2u : 1u);
+    p.map.nf = 24u - p.map.rc;
+    p.map.base = p.map.flen >> p.map.r0;
     p.nd = (gsx2_bucket(key_span, p.map) + 1u + 127u) / 128u * 128u;
     if (p.nd > GSX2_MAX_D) return p;
     uint32_t ib = 1;

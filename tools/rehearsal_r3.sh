@@ -8,7 +8,7 @@ GSX_BENCH_FORCE_DIST=1 timeout -k 10 200 python bench.py --cpu-frames 0 --steps 
 GSX_BENCH_FORCE_DIST=1 timeout -k 10 300 python bench.py --cpu-frames 0 --steps 64 --splats 20000000 --distinct-views --no-extras > gpurun_out/r3/bench_cfg4_n1.json 2> gpurun_out/r3/bench_cfg4_n1.err || exit 1
 # the sort harness: every kernel of the two-pass sort bracketed by events, checked against std::sort on the host
 # (arguments: splats scene reps [top-digit bits, 0 = the plan's] [camera inside the scene box] [third k2_local instance launched])
-for args in "6000000 clustered 20" "6000000 uniform 20" "6000000 tight 20" "1000000 uniform 20" "20000000 clustered 10 12" "20000000 clustered 10" "20000000 clustered 10 0 0 1" "20000000 uniform 10 0 0 1" "12000000 clustered 10 0 0 1" "6000000 clustered 20 0 1"; do
+for args in "6000000 clustered 20" "6000000 uniform 20" "6000000 tight 20" "1000000 uniform 20" "20000000 clustered 10 12" "20000000 clustered 10" "20000000 clustered 10 0 0 1" "20000000 uniform 10 0 0 1" "20000000 clustered 10 0 1 1" "12000000 clustered 10 0 0 1" "6000000 clustered 20 0 1"; do
   echo "== tools/sort2bench $args"
   timeout -k 10 120 tools/sort2bench $args || exit 1
 done > gpurun_out/r3/sort2bench.txt 2>&1
