@@ -277,3 +277,17 @@ def test_facade_compiles_with_the_callers_glm(tmp_path):
     subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(pkg_dir, "host"), "-I", os.path.join(root, "include"), "-I", "/root/reference",
                            os.path.join(root, "tests", "cpp", "glm_switch_test.cpp"), "-o", str(exe), "-L", pkg_dir, "-lgsx", f"-Wl,-rpath,{pkg_dir}"])
     assert subprocess.run([str(exe)], capture_output=True).returncode == 0
+
+
+def test_sort_plans_and_bucket_maps():
+    """tests/cpp/sort_plan_test (host-only, built with the library): every plan shape of the two-pass depth sort - narrow and wide key
+    ranges, 6 M to 24 M keys, the 13-bit plans of round 3 - maps keys to buckets monotonically, below the table size, and every
+    bucket is exactly the aligned block of keys its low bits span."""
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "cpp", "sort_plan_test")
+    if not os.path.exists(exe):
+        pytest.skip("tests/cpp/sort_plan_test not built (python __graft_entry__.py)")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith("bad 0"), r.stdout[-2000:]
+    assert "flen 0x1800000" in r.stdout and "nd 7296" in r.stdout       # (the wide 13-bit plan was among them)
