@@ -684,5 +684,25 @@ def test_cfg3_octree_orbit_at_6m(gsx_fresh, pkg, oracle, synth):
     assert gsx.select_octree(vp, 1e9) == 1 and gsx.selection()[0] == 0
     m = gsx.select_octree(vp, 0.0)
     assert m == int(t.is_leaf.sum()) and np.array_equal(gsx.selection(), np.nonzero(t.is_leaf)[0].astype(np.uint32))
+    # Two contexts on one GPU cutting at the same time, frames running beside the cuts: the one-launch compaction's workgroups
+    # wait for each other's counts, and here they share the GPU with a second grid of the same kind and with rasterizer launches.
+    vps, cuts = [], []
+    for f in (3, 33, 63, 93):
+        world, _ = oracle.orbit_world(5.0, (0.0, 1.0, 0.0), 2.0 * np.pi / 120.0, f)
+        view, proj, vp, cam = oracle.camera(world, 45.0, w / h)
+        gsx.select_octree(vp, 0.002)
+        vps.append((vp, cam, pkg.make_uniforms(proj, view)))
+        cuts.append(gsx.selection())
+    with pkg.Gsx(0) as g2:
+        t.upload(g2)
+        for rep in range(6):
+            for k in range(4):
+                a, b = vps[k], vps[(k + rep + 1) % 4]
+                gsx.select_octree(a[0], 0.002, want_count=False); gsx.sort(a[1], download=False); gsx.render(a[2], w, h, download=False)
+                g2.select_octree(b[0], 0.002, want_count=False); g2.sort(b[1], download=False); g2.render(b[2], w, h, download=False)
+                gsx.select_octree(b[0], 0.002, want_count=False)
+                g2.select_octree(a[0], 0.002, want_count=False)
+                assert np.array_equal(gsx.selection(), cuts[(k + rep + 1) % 4])
+                assert np.array_equal(g2.selection(), cuts[k])
     gsx.select_all()
     t.close()
