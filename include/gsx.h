@@ -107,7 +107,7 @@ const char* gsx_last_error(const gsx_ctx* ctx);
 int gsx_sync(gsx_ctx* ctx);
 /* 0 = no events (default).  1 = HIP events around every stage and every radix scatter launch
  * (gsx_get_timings fills all *_ms fields; the ~20 events cost tens of microseconds per frame).
- * 2 = sampled: every 8th sort (option "sample_every") carries events, alternately (a) one pair around every HBM pass of the
+ * 2 = sampled: every 8th sort (option "sample_every") carries events, in turn (alternately; option "sample_whole_every") (a) one pair around every HBM pass of the
  * sort - the k_radix_scatter launches of the LSD form, or the partition kernel and the bucket-sort kernels of the two-pass form
  * (gsx_timings.sort_form == 2: "pass" 0 and 1) - and (b) one pair around keys + sort as a whole (scatter_ms = the latest
  * sampled launch, scatter_sample says which pass).  A sampled sort runs on the main stream behind every queued frame, and what
