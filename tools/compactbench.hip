@@ -130,6 +130,62 @@ __global__ __launch_bounds__(256) void k_stamp(const uint32_t* __restrict__ ids,
     else flags[ids[i]] = stamp;
 }
 
+// experiment: one BIT per node (set with an atomic OR, cleared by the compaction that reads it) instead of a stamped byte
+__global__ __launch_bounds__(256) void k_stamp_bits(const uint32_t* __restrict__ ids, uint32_t m, uint32_t* __restrict__ bits) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= m) return;
+    const uint32_t id = ids[i];
+    atomicOr(&bits[id >> 5], 1u << (id & 31u));
+}
+template <int NT>
+__global__ __launch_bounds__(NT) void k_compact_bits(uint32_t* __restrict__ bits, uint32_t n, uint64_t* __restrict__ agg, uint32_t seq,
+                                                     uint32_t* __restrict__ out, uint32_t* __restrict__ m_out) {
+    __shared__ uint32_t s_tmp[NT / 64];
+    __shared__ uint32_t s_prefix;
+    const uint32_t tid = threadIdx.x, units = (n + 127u) / 128u;           // 16 bytes = 128 nodes per thread
+    const uint32_t u = blockIdx.x * NT + tid;
+    uint4 w = make_uint4(0u, 0u, 0u, 0u);
+    if (u < units) {
+        w = reinterpret_cast<const uint4*>(bits)[u];
+        if (w.x | w.y | w.z | w.w) reinterpret_cast<uint4*>(bits)[u] = make_uint4(0u, 0u, 0u, 0u);   // cleared for the next cut
+    }
+    const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
+    const uint32_t cnt = __popc(w.x) + __popc(w.y) + __popc(w.z) + __popc(w.w);
+    uint32_t total;
+    const uint32_t excl = gsx_block_excl_scan<NT>(cnt, s_tmp, &total);
+    if (tid == 0) __hip_atomic_store(&agg[blockIdx.x], (static_cast<uint64_t>(seq) << 32) | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid < 64u) {
+        uint32_t sum = 0;
+        for (uint32_t p = tid; p < blockIdx.x; p += 64u) {
+            uint64_t v = __hip_atomic_load(&agg[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (uint32_t spins = 0; static_cast<uint32_t>(v >> 32) != seq && spins < (1u << 20); ++spins) {
+                __builtin_amdgcn_s_sleep(2);
+                v = __hip_atomic_load(&agg[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (static_cast<uint32_t>(v >> 32) == seq) sum += static_cast<uint32_t>(v);
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+        if (tid == 0) s_prefix = sum;
+    }
+    __syncthreads();
+    const uint32_t run = s_prefix;
+    if (blockIdx.x == gridDim.x - 1 && tid == 0) *m_out = run + total;
+    if (run + total > n) return;
+    uint32_t pos = run + excl;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        uint32_t b = ww[q];
+        while (b) {
+            const uint32_t k = static_cast<uint32_t>(__ffs(static_cast<int>(b))) - 1u;
+            const uint32_t id = u * 128u + 32u * q + k;
+            if (id < n) out[pos] = id;
+            ++pos;
+            b &= b - 1u;
+        }
+    }
+}
+
 int main(int argc, char** argv) {
     const uint32_t n = argc > 1 ? (uint32_t)atoll(argv[1]) : 8484260u;
     const int reps = argc > 2 ? atoi(argv[2]) : 30;
@@ -226,6 +282,32 @@ int main(int argc, char** argv) {
             }
             printf("behind %zu scattered byte stores (%s): stores %.2f us, compaction %.2f us  %s\n", order.size(), mode ? "nontemporal" : "plain", sum_st * 1000.f / reps,
                    sum * 1000.f / reps, check("behind stores") ? "ok" : "WRONG");
+        }
+    }
+    {   // one bit per node: atomic OR stores, a compaction that reads 1 MB instead of 8.5 and clears what it read
+        std::vector<uint32_t> order(ref);
+        for (size_t b = 0; b + 8 <= order.size(); b += 8) { const size_t o = (rng() % (order.size() / 8)) * 8; for (int k = 0; k < 8; ++k) std::swap(order[b + k], order[o + k]); }
+        uint32_t *d_ids, *d_bits; CK(hipMalloc(&d_ids, order.size() * 4)); CK(hipMemcpy(d_ids, order.data(), order.size() * 4, hipMemcpyHostToDevice));
+        const uint32_t words = ((n + 127) / 128) * 4; CK(hipMalloc(&d_bits, words * 4)); CK(hipMemset(d_bits, 0, words * 4));
+        const uint32_t m = (uint32_t)order.size(), units128 = (n + 127) / 128;
+        for (int nt : {256, 512}) {
+            const uint32_t g = (units128 + nt - 1) / nt;
+            float sum = 0, sum_st = 0; bool ok = true;
+            for (int i = 0; i < reps + 3; ++i) {
+                hipEvent_t a, b, c0; CK(hipEventCreate(&a)); CK(hipEventCreate(&b)); CK(hipEventCreate(&c0));
+                if (i == 0) CK(hipMemset(d_out, 0xFF, (size_t)n * 4));
+                CK(hipEventRecord(c0, 0));
+                hipLaunchKernelGGL(k_stamp_bits, dim3((m + 255) / 256), dim3(256), 0, 0, d_ids, m, d_bits);
+                CK(hipEventRecord(a, 0));
+                if (nt == 256) hipLaunchKernelGGL(k_compact_bits<256>, dim3(g), dim3(256), 0, 0, d_bits, n, d_agg, ++seq, d_out, d_m);
+                else hipLaunchKernelGGL(k_compact_bits<512>, dim3(g), dim3(512), 0, 0, d_bits, n, d_agg, ++seq, d_out, d_m);
+                CK(hipEventRecord(b, 0)); CK(hipEventSynchronize(b));
+                float ms, ms2; CK(hipEventElapsedTime(&ms, a, b)); CK(hipEventElapsedTime(&ms2, c0, a));
+                if (i >= 3) { sum += ms; sum_st += ms2; }
+                if (i == 0 || i == reps + 2) ok = ok && check("bits");
+                CK(hipEventDestroy(a)); CK(hipEventDestroy(b)); CK(hipEventDestroy(c0));
+            }
+            printf("one BIT per node, NT %d (%u workgroups): %zu atomic ORs %.2f us, compaction %.2f us  %s\n", nt, g, order.size(), sum_st * 1000.f / reps, sum * 1000.f / reps, ok ? "ok" : "WRONG");
         }
     }
     for (uint32_t upt : {3u, 2u, 1u}) {
