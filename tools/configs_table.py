@@ -55,6 +55,7 @@ def cfg1():
 
 def cfg3():
     n, W, H, frames = 6_000_000, 1920, 1080, 120
+    timed = int(os.environ.get("GSX_CFG3_FRAMES", frames))      # (PMC passes: fewer frames, same orbit)
     t0 = time.perf_counter()
     tree = lod.build_octree(synth.clustered_cloud(n, seed=6))
     build_s = time.perf_counter() - t0
@@ -80,7 +81,7 @@ def cfg3():
             g.select_octree(poses[0][2], 0.002, want_count=False)
             g.sort(poses[0][1], download=False)
         t0 = time.perf_counter()
-        for f in range(frames):
+        for f in range(timed):
             u, pos, vp = poses[f]
             if ahead:
                 _, npos, nvp = poses[(f + 1) % frames]
@@ -91,9 +92,9 @@ def cfg3():
                 g.sort(pos, download=False)
             g.render(u, W, H, download=False)
         g.sync()
-        dt = (time.perf_counter() - t0) / frames
+        dt = (time.perf_counter() - t0) / timed
         t = g.timings()
-    emit({"config": "cfg3", "splats": n, "octree_nodes": int(tree.n), "host_octree_build_s": build_s, "frames": frames,
+    emit({"config": "cfg3", "splats": n, "octree_nodes": int(tree.n), "host_octree_build_s": build_s, "frames": timed,
           "what": "octree cut (threshold 0.002) -> sort -> 1080p frame per orbit step", "cut_sizes_at_frames_0_30_60_90": ms,
           "ms_per_frame": dt * 1e3, "fps": 1.0 / dt, "last_frame_tile_pairs": t["tile_pairs"], "last_frame_iters": t["render_iters"],
           "call_order": "cut + sort f+1, render f (sort_ahead)" if ahead else "cut, sort, render f",
