@@ -469,6 +469,16 @@ def main():
     # previous frame only to check whether it needs more iterations).  Nothing is read back inside the loop: the sampled
     # launches sit in the library's event ring and are collected after the closing fence.
     stamps = [] if os.environ.get("GSX_BENCH_STEPTIMES") else None    # (diagnostic: host time after every step's calls)
+    calls = []
+    if stamps is not None:                               # (diagnostic: host time inside every library call of the loop)
+        def _timed(name, fn):
+            def w(*x, **kw):
+                t = time.perf_counter()
+                r = fn(*x, **kw)
+                calls.append((name, t - t0, time.perf_counter() - t))
+                return r
+            return w
+        g.sort, g.render = _timed("sort", g.sort), _timed("render", g.render)
     t0 = time.perf_counter()
     for i in range(a.steps):
         step()
@@ -480,6 +490,9 @@ def main():
     _dbg("timed region closed")
     if stamps is not None and rank == 0:
         np.save(os.environ["GSX_BENCH_STEPTIMES"], np.asarray(stamps))
+        with open(os.environ["GSX_BENCH_STEPTIMES"] + ".calls.txt", "w") as fh:
+            for name, at, dur in calls:
+                fh.write(f"{at * 1e3:9.3f} ms  {name:6s} {dur * 1e6:8.1f} us\n")
     per_pass, pass_n = g.scatter_samples(reset=True)     # mean launch duration of each radix pass over the timed region
     sort_ms_timed, sort_n_timed = g.sort_samples(reset=True)
     t = g.timings()

@@ -28,6 +28,17 @@ def orbit_pose(distance, rotations):
     return out
 
 
+def orbit_events(events4, distance=5.0, orbit_rate=1.0, scroll_rate=1.0):
+    """World matrix of the orbit camera after window events (OrbitCamera.h:32-74 as main.cpp:139-155 forwards them):
+    rows {0, xpos, ypos, dt} cursor moved, {1, button, action, -} mouse button, {2, yoffset, -, dt} scrolled."""
+    ev = np.ascontiguousarray(events4, np.float64).reshape(-1, 4)
+    out = np.empty(16, np.float32)
+    rc = _lib().gsx_host_orbit_events(C.c_float(distance), C.c_float(orbit_rate), C.c_float(scroll_rate), _p(ev) if len(ev) else None,
+                                      C.c_uint32(len(ev)), _p(out))
+    assert rc == 0
+    return out
+
+
 def orbit_world(distance, azimuth, elevation):
     """Camera at `distance`, orbit node rotated about +Y by azimuth then about its local X by elevation."""
     rots = []

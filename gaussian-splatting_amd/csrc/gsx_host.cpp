@@ -130,6 +130,25 @@ int gsx_host_orbit_pose(float distance, const float* axes3, const float* angles,
     return GSX_OK;
 }
 
+int gsx_host_orbit_events(float distance, float orbit_rate, float scroll_rate, const double* events4, uint32_t n_events, float world16[16]) {
+    if (!world16 || (n_events && !events4)) return GSX_E_INVALID;
+    auto scene = std::make_shared<Node>();
+    auto orbit = std::make_shared<OrbitCamera>(distance);
+    scene->addChild(orbit);
+    orbit->orbitRate = orbit_rate;       // main.cpp:235-236
+    orbit->scrollRate = scroll_rate;
+    for (uint32_t i = 0; i < n_events; ++i) {
+        const double* e = events4 + 4 * static_cast<size_t>(i);
+        if (e[0] == 0.0) orbit->onMouseMove(e[1], e[2], e[3]);                                              // main.cpp:139-141
+        else if (e[0] == 1.0) orbit->onMouseButton(static_cast<int>(e[1]), static_cast<int>(e[2]));        // main.cpp:143-151
+        else if (e[0] == 2.0) orbit->onScroll(e[1], e[3]);                                                  // main.cpp:153-155
+        else return GSX_E_INVALID;
+    }
+    scene->updateWorldMatrix(mat4(1.0f));   // main.cpp:483-486
+    std::memcpy(world16, orbit->camera->worldMatrix.data(), 64);
+    return GSX_OK;
+}
+
 // ---- host-side LOD structures (construction is load-time CPU work) -----------------
 }  // extern "C"
 

@@ -35,6 +35,8 @@ inline vec3 operator/(vec3 a, float s) { return {a.x / s, a.y / s, a.z / s}; }
 // glm/detail/func_geometric.inl:47-55
 inline float dot(vec3 a, vec3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 inline float length(vec3 a) { return std::sqrt(dot(a, a)); }
+// glm/detail/func_geometric.inl:86-98
+inline vec3 cross(vec3 x, vec3 y) { return {x.y * y.z - y.y * x.z, x.z * y.x - y.z * x.x, x.x * y.y - y.x * x.y}; }
 // glm/detail/func_geometric.inl:16-23: distance(p0, p1) = length(p1 - p0)
 inline float distance(vec3 p0, vec3 p1) { return length(p1 - p0); }
 

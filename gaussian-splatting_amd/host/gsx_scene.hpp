@@ -1,8 +1,8 @@
 // gsx_scene.hpp — scene-graph inputs of the path: Node (Node.h:8-36, Node.cpp:10-27),
-// Camera (Camera.h:9-35) and OrbitCamera's pose construction (OrbitCamera.h:24-30),
-// on gsx_math.  Only what produces the matrices the path consumes; UI handlers
-// (mouse/scroll) are out of scope.
+// Camera (Camera.h:9-35) and OrbitCamera (OrbitCamera.h:8-75: pose construction and the
+// mouse / scroll handlers the viewer front end forwards, host/gsx_viewer.hpp), on gsx_math.
 #pragma once
+#include <algorithm>
 #include <memory>
 #include <vector>
 
@@ -53,6 +53,43 @@ public:
     std::shared_ptr<Camera> camera = std::make_shared<Camera>();
     OrbitCamera() { children.push_back(camera); }
     explicit OrbitCamera(float distance) : OrbitCamera() { camera->position = vec3(0.0f, 0.0f, distance); }
+
+    float scrollRate = 5.0f, minDistance = 0.1f;      // OrbitCamera.h:18-22
+    float orbitRate = 0.3f, maxOrbitRate = 0.5f;
+
+    // OrbitCamera.h:32-37: the dolly runs in double and is rounded once into the float position
+    void onScroll(double yoffset, double deltaTime) {
+        camera->position.z = static_cast<float>(static_cast<double>(camera->position.z) + scrollRate * yoffset * (-1) * deltaTime);
+        if (camera->position.z < minDistance) camera->position.z = minDistance;
+    }
+    void onMouseButton(int button, int action) {      // OrbitCamera.h:39-43: left button, 1 = pressed
+        if (button == 0) pressed = action == 1;
+    }
+    void onMouseMove(double xpos, double ypos, double deltaTime) {   // OrbitCamera.h:45-49
+        orbit(xpos, ypos, deltaTime);
+        p_xpos = xpos;
+        p_ypos = ypos;
+    }
+    // OrbitCamera.h:51-74: yaw about world +Y, pitch about the node's own X axis, both clamped per event; a pitch that
+    // would carry the camera over the pole (its forward axis turning against the horizontal forward) is taken back.
+    void orbit(double xpos, double ypos, double deltaTime) {
+        if (!pressed) return;
+        float dx = static_cast<float>(xpos - p_xpos);
+        float dy = static_cast<float>(ypos - p_ypos);
+        const float rate = static_cast<float>(orbitRate * deltaTime);
+        dx = std::min(maxOrbitRate, std::max(-maxOrbitRate, dx * rate));
+        dy = std::min(maxOrbitRate, std::max(-maxOrbitRate, dy * rate));
+        rotate(vec3(0.0f, 1.0f, 0.0f), -dx);
+        rotate(rotation[0], -dy);
+        const vec3 cameraForward = rotation * vec3(0.0f, 0.0f, -1.0f);
+        const vec3 cameraRight = rotation * vec3(1.0f, 0.0f, 0.0f);
+        const vec3 forward = cross(cameraRight, vec3(0.0f, 1.0f, 0.0f));
+        if (dot(forward, cameraForward) > 0) rotate(rotation[0], dy);
+    }
+
+private:
+    double p_xpos = 0.0, p_ypos = 0.0;   // (uninitialised in the reference: a press before the first move is undefined there)
+    bool pressed = false;
 };
 
 }  // namespace gsx

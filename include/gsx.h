@@ -330,6 +330,13 @@ int gsx_host_camera(const float world16[16], float fov_deg, float aspect, float 
  * Node::rotate(axis_i, angle_i) calls on the orbit node (OrbitCamera.h:24-30,
  * Node.cpp:10-27, main.cpp:469-486). */
 int gsx_host_orbit_pose(float distance, const float* axes3, const float* angles, uint32_t n_rot, float world16[16]);
+/* The same camera driven by window events as the reference's Application forwards them (main.cpp:139-155,235-236 ->
+ * OrbitCamera.h:32-74): events4 holds n_events rows of 4 doubles, {0, xpos, ypos, deltaTime} = cursor moved,
+ * {1, button, action, -} = mouse button (button 0, action 1 = pressed), {2, yoffset, -, deltaTime} = scrolled;
+ * orbit_rate / scroll_rate are GUI::Parameters' (gui.hpp:22-23).  The optional viewer front end (host/gsx_viewer.hpp) runs
+ * on the same handlers. */
+int gsx_host_orbit_events(float distance, float orbit_rate, float scroll_rate, const double* events4, uint32_t n_events,
+                          float world16[16]);
 
 /* ---- host-side LOD structures: Octree (Octree.cpp:33-187), HC (HC.cpp:4-98), GridHC
  * (GridHC.cpp:10-74) built on the CPU exactly as the reference builds them at load time

@@ -240,6 +240,13 @@ class Reference:
                                  C.c_uint32(steps), _opt(out), _opt(rot))
         return out, rot
 
+    def orbit_events(self, events4, distance=5.0, orbit_rate=1.0, scroll_rate=1.0):
+        """OrbitCamera.h:32-74 driven like main.cpp:139-155; rows {0,x,y,dt} cursor, {1,button,action,-}, {2,yoffset,-,dt} scroll."""
+        ev = np.ascontiguousarray(events4, np.float64).reshape(-1, 4)
+        out = np.empty(16, np.float32)
+        self.lib.ref_orbit_events(C.c_float(distance), C.c_float(orbit_rate), C.c_float(scroll_rate), _opt(ev), C.c_uint32(len(ev)), _opt(out))
+        return out
+
     def bb_screen_area(self, bb16, world, fov=45.0, aspect=1.0, near=0.1, far=100.0):
         return self.lib.ref_bb_screen_area(_opt(np.ascontiguousarray(bb16, np.float32)),
                                            _opt(np.ascontiguousarray(world, np.float32)), C.c_float(fov),

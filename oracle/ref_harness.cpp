@@ -32,6 +32,7 @@
 #include "Octree.hpp"
 #include "HC.hpp"
 #include "GridHC.hpp"
+#include "OrbitCamera.h"
 
 static_assert(sizeof(Splat) == 80, "Splat is the 80-B GPU record");
 static_assert(sizeof(SplatRaw) == 32, "SplatRaw is the 32-B file record");
@@ -141,6 +142,26 @@ void ref_camera_matrices(const float world16[16], float fov, float aspect, float
     std::memcpy(view16, &v[0][0], 64);
     std::memcpy(proj16, &p[0][0], 64);
 }
+// The reference's OrbitCamera (OrbitCamera.h:8-75, header only) driven by window events the way Application forwards
+// them (main.cpp:139-155,235-236): rows of 4 doubles {0,x,y,dt} cursor, {1,button,action,-}, {2,yoffset,-,dt} scroll.
+// Every sequence starts with a cursor event while no button is down (the reference leaves p_xpos / p_ypos
+// uninitialised until the first one).
+void ref_orbit_events(float distance, float orbit_rate, float scroll_rate, const double* ev, uint32_t n, float world16[16]) {
+    auto scene = std::make_shared<Node>();
+    auto orbit = std::make_shared<OrbitCamera>(distance);
+    scene->addChild(orbit);
+    orbit->orbitRate = orbit_rate;
+    orbit->scrollRate = scroll_rate;
+    for (uint32_t i = 0; i < n; ++i) {
+        const double* e = ev + 4 * static_cast<size_t>(i);
+        if (e[0] == 0.0) orbit->onMouseMove(e[1], e[2], e[3]);
+        else if (e[0] == 1.0) orbit->onMouseButton(static_cast<int>(e[1]), static_cast<int>(e[2]));
+        else orbit->onScroll(e[1], e[3]);
+    }
+    scene->updateWorldMatrix(glm::mat4(1.0f));
+    std::memcpy(world16, &orbit->camera->worldMatrix[0][0], 64);
+}
+
 // Orbit pose exactly as main.cpp:90-93,469-486 builds it: scene -> OrbitCamera(distance)
 // -> camera; `steps` successive Node::rotate(axis, angle) calls on the orbit node.
 void ref_orbit_world(float distance, const float axis[3], float angle, uint32_t steps, float world16[16],

@@ -291,3 +291,42 @@ def test_sort_plans_and_bucket_maps():
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and r.stdout.strip().endswith("bad 0"), r.stdout[-2000:]
     assert "flen 0x1800000" in r.stdout and "nd 7296" in r.stdout       # (the wide 13-bit plan was among them)
+
+
+# ---- viewer front end: OrbitCamera's input handlers (host/gsx_scene.hpp) vs the reference's own OrbitCamera.h ----
+def test_orbit_camera_events_match_reference(pkg):
+    """onMouseMove / onMouseButton / onScroll as main.cpp:139-155 forwards them (OrbitCamera.h:32-74): the camera's world matrix
+    after EVERY prefix of each event sequence, bit for bit (drags, the pole rule, per-event clamps, the dolly's floor)."""
+    cam = importlib.import_module("gaussian_splatting_amd.camera")
+    g = golden("viewer_orbit.npz")
+    moved = 0
+    for name in g["names"]:
+        ev, (dist, orate, srate), want = g[f"{name}_events"], g[f"{name}_params"], g[f"{name}_world"]
+        for k in range(len(ev) + 1):
+            got = cam.orbit_events(ev[:k], float(dist), float(orate), float(srate))
+            assert np.array_equal(bits(got), bits(want[k])), (str(name), k)
+        moved += int(not np.array_equal(want[0], want[-1]))
+    assert moved >= 8                                       # (the sequences do turn and dolly the camera)
+    w = g["scroll_world"]
+    assert w[-1][14] == np.float32(0.1) and w[0][14] == np.float32(5.0)          # OrbitCamera.h:34-36: minDistance
+    assert np.array_equal(g["right_button_is_ignored_world"][3], g["right_button_is_ignored_world"][0])
+
+
+def test_orbit_camera_events_match_live_reference(pkg, reference):
+    cam = importlib.import_module("gaussian_splatting_amd.camera")
+    rng = np.random.default_rng(77)
+    for trial in range(6):
+        ev = [[0.0, 500.0, 400.0, 1 / 60]]
+        x, y = 500.0, 400.0
+        for _ in range(200):
+            r = rng.random()
+            if r < 0.7:
+                x += float(rng.normal(0, 40)); y += float(rng.normal(0, 40))
+                ev.append([0.0, x, y, float(rng.choice([1 / 144, 1 / 60, 0.1]))])
+            elif r < 0.85:
+                ev.append([1.0, float(rng.integers(0, 2)), float(rng.integers(0, 2)), 0.0])
+            else:
+                ev.append([2.0, float(rng.normal(0, 3)), 0.0, float(rng.choice([1 / 60, 0.25]))])
+        ev = np.asarray(ev)
+        d, o, s = float(rng.uniform(0.2, 9)), float(rng.uniform(0.01, 2)), float(rng.uniform(0.1, 20))
+        assert np.array_equal(bits(cam.orbit_events(ev, d, o, s)), bits(reference.orbit_events(ev, d, o, s))), trial
