@@ -330,3 +330,17 @@ def test_orbit_camera_events_match_live_reference(pkg, reference):
         ev = np.asarray(ev)
         d, o, s = float(rng.uniform(0.2, 9)), float(rng.uniform(0.01, 2)), float(rng.uniform(0.1, 20))
         assert np.array_equal(bits(cam.orbit_events(ev, d, o, s)), bits(reference.orbit_events(ev, d, o, s))), trial
+
+
+def test_viewer_script_layer():
+    """The viewer front end's host-only layer (host/gsx_viewer.hpp): script grammar, slider ranges (gui.cpp:58-122), frame clock; and
+    the program's usage errors.  (Frames need the GPU: tests/test_gpu_facade.py::test_viewer_front_end.)"""
+    import os
+    import subprocess
+    from conftest import ROOT
+    r = subprocess.run([os.path.join(ROOT, "tests", "cpp", "viewer_script_test")], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0 and r.stdout.strip() == "ok", r.stdout + r.stderr
+    exe = os.path.join(ROOT, "gaussian-splatting_amd", "gsx_view")
+    for args in ([], ["scene.splat", "--size", "0x0"], ["scene.splat", "--bogus"], ["scene.splat", "--mesh"]):
+        r = subprocess.run([exe] + args, capture_output=True, text=True, timeout=60)
+        assert r.returncode == 2 and "gsx_view" in r.stderr, args
