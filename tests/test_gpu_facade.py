@@ -211,6 +211,18 @@ def test_viewer_front_end(tmp_path, pkg, synth, oracle):
     assert r.returncode == 0 and "2 frames presented" in r.stderr, r.stdout + r.stderr
     octf = np.fromfile(tmp_path / "oct.rgba", np.uint8).reshape(2, H, W, 4)
     assert octf[..., :3].std() > 3 and not np.array_equal(octf[0], octf[1])
+    # the two clustered meshes (SplatMeshHC keeps 500 splats, SplatMeshHC.hpp:72-75; GridHC is the reference's choice): the `depth` slider
+    # moves the view-independent cut, so the frame changes with it while the camera rests
+    small = tmp_path / "small.splat"
+    synth.uniform_cloud(3000, seed=17, half_extent=1.5).tofile(small)
+    for mesh in ("hc", "gridhc"):
+        r = subprocess.run([exe, str(small), "--mesh", mesh, "--size", f"{W}x{H}", "--events", "-", "--raw", str(tmp_path / f"{mesh}.rgba"), "--stats", "1"],
+                           input="set depth 2\nframe 2\nset depth 400\nframe\n", capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0 and "3 frames presented" in r.stderr, r.stdout + r.stderr
+        f = np.fromfile(tmp_path / f"{mesh}.rgba", np.uint8).reshape(3, H, W, 4)
+        assert np.array_equal(f[0], f[1]) and not np.array_equal(f[1], f[2]) and f[..., :3].std() > 3, mesh
+        drawn = [int(line.split()[-3]) for line in r.stderr.splitlines() if line.endswith("splats drawn")]
+        assert len(drawn) == 2 and drawn[0] < drawn[1], (mesh, drawn)      # (no rate yet after the first frame) a deeper cut draws more splats
     # errors are loud: a slider that does not exist, a line that is no event
     # (bayerSize 3: the slider of gui.cpp:60 allows it, the shader's Bayer matrix does not exist for it; gsx_render rejects the block)
     for bad, what in (("set nosuch 1\nframe\n", "viewer script"), ("wiggle 3\n", "viewer script"), ("set bayerSize 3\nframe\n", "bayerSize")):
