@@ -24,6 +24,7 @@
 #pragma once
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <deque>
 #include <fstream>
 #include <istream>
@@ -51,7 +52,16 @@ inline bool parse_viewer_event(const std::string& line, ViewerEvent& ev) {
     else if (word == "scroll") { ev.kind = ViewerEvent::Scroll; need(ev.a); }
     else if (word == "set") { ev.kind = ViewerEvent::Set; if (!(in >> ev.name)) throw std::invalid_argument("viewer script: `set` without a name"); need(ev.a); }
     else if (word == "dt") { ev.kind = ViewerEvent::DeltaTime; need(ev.a); }
-    else if (word == "frame") { ev.kind = ViewerEvent::Frame; ev.a = 1.0; in >> ev.a; if (!(ev.a >= 0.0)) throw std::invalid_argument("viewer script: bad frame count in `" + line + "`"); }
+    else if (word == "frame") {
+        ev.kind = ViewerEvent::Frame;
+        ev.a = 1.0;
+        std::string count;
+        if (in >> count) {
+            char* end = nullptr;
+            ev.a = std::strtod(count.c_str(), &end);
+            if (end == count.c_str() || *end || !(ev.a >= 0.0)) throw std::invalid_argument("viewer script: bad frame count in `" + line + "`");
+        }
+    }
     else if (word == "quit") { ev.kind = ViewerEvent::Quit; }
     else throw std::invalid_argument("viewer script: unknown line `" + line + "`");
     return true;

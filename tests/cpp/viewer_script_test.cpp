@@ -25,7 +25,8 @@ int main() {
     CHECK(parse_viewer_event("frame 7", e) && e.a == 7.0);
     CHECK(parse_viewer_event("quit", e) && e.kind == ViewerEvent::Quit);
     CHECK(throws([&] { parse_viewer_event("move 1", e); }) && throws([&] { parse_viewer_event("jump 1 2", e); }) &&
-          throws([&] { parse_viewer_event("set", e); }) && throws([&] { parse_viewer_event("frame -1", e); }));
+          throws([&] { parse_viewer_event("set", e); }) && throws([&] { parse_viewer_event("frame -1", e); }) &&
+          throws([&] { parse_viewer_event("frame many", e); }) && throws([&] { parse_viewer_event("frame 3x", e); }));
 
     GUI::Parameters p;                                   // gui.hpp:16-30 defaults
     CHECK(p.splatSize == 1.0f && p.cutOff == 3.5f && p.fov == 45.0f && p.bayerSize == 1u && p.orbitRate == 1.0f && p.min_screen_area == 0.2f);
