@@ -25,7 +25,7 @@ ABI_SYMBOLS = [
     "gsx_set_lod_hc", "gsx_select_octree", "gsx_select_hc", "gsx_select_band", "gsx_get_selection", "gsx_sort", "gsx_sort_noalloc", "gsx_get_sorted_dev",
     "gsx_get_keys", "gsx_render", "gsx_get_framebuffer_dev", "gsx_set_framebuffer_dev", "gsx_get_stream",
     "gsx_comm_unique_id", "gsx_comm_init", "gsx_comm_destroy", "gsx_gather",
-    "gsx_host_convert_raw", "gsx_host_load_splat_file", "gsx_host_free", "gsx_host_load_ply_raw", "gsx_host_load_ply_file", "gsx_host_camera", "gsx_host_orbit_pose", "gsx_host_orbit_events",
+    "gsx_host_convert_raw", "gsx_host_load_splat_file", "gsx_host_free", "gsx_host_alloc_pinned", "gsx_host_free_pinned", "gsx_host_load_ply_raw", "gsx_host_load_ply_file", "gsx_host_camera", "gsx_host_orbit_pose", "gsx_host_orbit_events",
     "gsx_host_octree_build", "gsx_host_hc_build", "gsx_host_gridhc_build", "gsx_host_lod_free", "gsx_host_lod_size",
     "gsx_host_lod_roots", "gsx_host_lod_cells", "gsx_host_lod_splats", "gsx_host_lod_flat_octree", "gsx_host_lod_flat_hc",
     "gsx_host_lod_cut_depth", "gsx_host_lod_cut_camera",

@@ -3,7 +3,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <ctime>
+#include <mutex>
 #include <new>
+#include <unordered_set>
 #include <vector>
 
 #include "gsx_internal.h"
@@ -854,6 +856,33 @@ int gsx_set_framebuffer_dev(gsx_ctx* c, void* rgba8_dev, uint64_t capacity_bytes
     c->fb_ext = static_cast<uint8_t*>(rgba8_dev);
     c->fb_ext_cap = rgba8_dev ? capacity_bytes : 0;
     return GSX_OK;
+}
+
+// Page-locked frames for synchronous readers (include/gsx.h).  The set remembers which pointers hipHostMalloc gave out, so a
+// block that had to come from malloc is released the right way too.
+static std::mutex g_pinned_mu;
+static std::unordered_set<void*> g_pinned;
+
+void* gsx_host_alloc_pinned(uint64_t bytes) {
+    if (bytes == 0) bytes = 1;
+    void* p = nullptr;
+    if (hipHostMalloc(&p, bytes, hipHostMallocDefault) == hipSuccess && p) {
+        std::lock_guard<std::mutex> lk(g_pinned_mu);
+        g_pinned.insert(p);
+        return p;
+    }
+    (void)hipGetLastError();            // (no device, or no page-locked memory left: pageable memory serves)
+    return std::malloc(bytes);
+}
+
+void gsx_host_free_pinned(void* p) {
+    if (!p) return;
+    bool pinned;
+    {
+        std::lock_guard<std::mutex> lk(g_pinned_mu);
+        pinned = g_pinned.erase(p) != 0;
+    }
+    if (pinned) (void)hipHostFree(p); else std::free(p);
 }
 
 int gsx_get_stream(gsx_ctx* c, void** hip_stream) {

@@ -58,6 +58,25 @@ inline void glfwDestroyWindow(GLFWwindow* window) { delete window; }
 #endif
 
 namespace gsx {
+
+// Frames are read back from the GPU every render(): their bytes live in page-locked memory (gsx_host_alloc_pinned), which
+// the device writes by DMA without a staging copy.  A std::vector with this allocator, so `pixels->data()` / `size()` stay.
+template <typename T>
+struct PinnedAllocator {
+    using value_type = T;
+    PinnedAllocator() = default;
+    template <typename U> PinnedAllocator(const PinnedAllocator<U>&) {}
+    T* allocate(size_t n) {
+        void* p = gsx_host_alloc_pinned(static_cast<uint64_t>(n) * sizeof(T));
+        if (!p) throw std::bad_alloc();
+        return static_cast<T*>(p);
+    }
+    void deallocate(T* p, size_t) { gsx_host_free_pinned(p); }
+    template <typename U> bool operator==(const PinnedAllocator<U>&) const { return true; }
+    template <typename U> bool operator!=(const PinnedAllocator<U>&) const { return false; }
+};
+using FrameBytes = std::vector<uint8_t, PinnedAllocator<uint8_t>>;
+
 namespace wgpu {
 
 enum class BufferUsage : uint32_t { None = 0, CopyDst = 1, Storage = 2, Index = 4, Vertex = 8, Uniform = 16 };
@@ -115,7 +134,7 @@ struct Queue {
 struct BindGroup { Buffer uniforms; };           // binding 0 of main.cpp:441-467 (the 224-byte Uniforms block)
 struct TextureView {
     uint32_t width = 0, height = 0;
-    std::shared_ptr<std::vector<uint8_t>> pixels;   // RGBA8, row-major, y down
+    std::shared_ptr<FrameBytes> pixels;   // RGBA8, row-major, y down (page-locked)
     explicit operator bool() const { return static_cast<bool>(pixels); }
     void release() { pixels.reset(); }
 };
@@ -130,7 +149,7 @@ using ErrorCallback = std::function<void(ErrorType, const char*)>;   // webgpu.h
 // The swap chain of renderer.cpp:73-95,123-151: one RGBA8 frame in host memory that render() fills by readback.
 // present() hands it to `onPresent` (the optional viewer front end blits it); headless it is a no-op.
 struct Surface {
-    std::shared_ptr<std::vector<uint8_t>> frame;
+    std::shared_ptr<FrameBytes> frame;
     uint32_t width = 0, height = 0;
     std::function<void(const uint8_t* rgba8, uint32_t width, uint32_t height)> onPresent;
     void present() const { if (onPresent && frame) onPresent(frame->data(), width, height); }   // main.cpp:282
@@ -255,7 +274,7 @@ private:
         surface_format = TextureFormat::RGBA8Unorm;
         surface.width = static_cast<uint32_t>(width);
         surface.height = static_cast<uint32_t>(height);
-        surface.frame = std::make_shared<std::vector<uint8_t>>(static_cast<size_t>(width) * height * 4);
+        surface.frame = std::make_shared<FrameBytes>(static_cast<size_t>(width) * height * 4);
     }
 };
 

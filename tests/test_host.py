@@ -344,3 +344,21 @@ def test_viewer_script_layer():
     for args in ([], ["scene.splat", "--size", "0x0"], ["scene.splat", "--bogus"], ["scene.splat", "--mesh"]):
         r = subprocess.run([exe] + args, capture_output=True, text=True, timeout=60)
         assert r.returncode == 2 and "gsx_view" in r.stderr, args
+
+
+def test_pinned_host_memory_falls_back_without_a_gpu(pkg):
+    """gsx_host_alloc_pinned: page-locked when a GPU runtime is there, plain malloc otherwise; either way usable and freeable."""
+    import ctypes as C
+    lib = pkg.load_library()
+    lib.gsx_host_alloc_pinned.restype = C.c_void_p
+    lib.gsx_host_alloc_pinned.argtypes = [C.c_uint64]
+    lib.gsx_host_free_pinned.argtypes = [C.c_void_p]
+    for nbytes in (0, 1, 4096, 1920 * 1080 * 4):
+        p = lib.gsx_host_alloc_pinned(nbytes)
+        assert p
+        buf = (C.c_uint8 * max(nbytes, 1)).from_address(p)
+        buf[0] = 7
+        buf[max(nbytes, 1) - 1] = 9
+        assert buf[max(nbytes, 1) - 1] == 9
+        lib.gsx_host_free_pinned(p)
+    lib.gsx_host_free_pinned(None)
