@@ -224,6 +224,12 @@ def test_viewer_front_end(tmp_path, pkg, synth, oracle):
         drawn = [int(line.split()[-3]) for line in r.stderr.splitlines() if line.endswith("splats drawn")]
         assert len(drawn) == 2 and drawn[0] < drawn[1], (mesh, drawn)      # (no rate yet after the first frame) a deeper cut draws more splats
     # errors are loud: a slider that does not exist, a line that is no event
+    # the example script that ships with the program
+    example = os.path.join(ROOT, "gaussian-splatting_amd", "viewer", "orbit_drag.txt")
+    r = subprocess.run([exe, str(small), "--mesh", "gridhc", "--size", f"{W}x{H}", "--events", example, "--stats", "0", "--every", "10", "--out", str(out)],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "43 frames presented" in r.stderr, r.stdout + r.stderr
+    assert os.path.exists(out / "frame_00040.ppm") and not os.path.exists(out / "frame_00041.ppm")      # --every 10
     # (bayerSize 3: the slider of gui.cpp:60 allows it, the shader's Bayer matrix does not exist for it; gsx_render rejects the block)
     for bad, what in (("set nosuch 1\nframe\n", "viewer script"), ("wiggle 3\n", "viewer script"), ("set bayerSize 3\nframe\n", "bayerSize")):
         r = subprocess.run([exe, str(scene), "--size", f"{W}x{H}", "--events", "-"], input=bad, capture_output=True, text=True, timeout=300)
