@@ -127,8 +127,11 @@ inline float det3(const Cov3& a) {
            a.m[2][0] * (a.m[0][1] * a.m[1][2] - a.m[1][1] * a.m[0][2]);
 }
 // func_matrix.inl:269-291
-inline Cov3 inv3(const Cov3& a) {
-    const float ood = 1.0f / det3(a);
+inline Cov3 inv3_det(const Cov3& a, float det);
+inline Cov3 inv3(const Cov3& a) { return inv3_det(a, det3(a)); }
+// the same with the determinant already known (HC keeps one per node)
+inline Cov3 inv3_det(const Cov3& a, float det) {
+    const float ood = 1.0f / det;
     Cov3 r;
     r.m[0][0] = +(a.m[1][1] * a.m[2][2] - a.m[2][1] * a.m[1][2]) * ood;
     r.m[1][0] = -(a.m[1][0] * a.m[2][2] - a.m[2][0] * a.m[1][2]) * ood;
@@ -142,15 +145,17 @@ inline Cov3 inv3(const Cov3& a) {
     return r;
 }
 // one-directional term of Splat.h:169-183: 0.5 (tr(B^-1 A) + d^T B^-1 d - 3 + ln(det B / det A)), d = a - b
-inline float kl_term(const Cov3& A, vec3 pa, const Cov3& B, vec3 pb) {
+inline float kl_term_pre(const Cov3& A, vec3 pa, float detA, const Cov3& Bi, float detB, vec3 pb);
+inline float kl_term(const Cov3& A, vec3 pa, const Cov3& B, vec3 pb) { return kl_term_pre(A, pa, det3(A), inv3(B), det3(B), pb); }
+// the same with B's inverse and both determinants already known: pure functions of A and B, so caching them changes no bit
+inline float kl_term_pre(const Cov3& A, vec3 pa, float detA, const Cov3& Bi, float detB, vec3 pb) {
     const vec3 d = pa - pb;
-    const Cov3 Bi = inv3(B);
     float diag[3];                                       // diagonal of Bi * A (type_mat3x3.inl:486-519)
     for (int j = 0; j < 3; ++j) diag[j] = Bi.m[0][j] * A.m[j][0] + Bi.m[1][j] * A.m[j][1] + Bi.m[2][j] * A.m[j][2];
     const float trace_term = diag[0] + diag[1] + diag[2];
     const vec3 Bd(Bi.m[0][0] * d.x + Bi.m[1][0] * d.y + Bi.m[2][0] * d.z, Bi.m[0][1] * d.x + Bi.m[1][1] * d.y + Bi.m[2][1] * d.z,
                   Bi.m[0][2] * d.x + Bi.m[1][2] * d.y + Bi.m[2][2] * d.z);
-    const float det_term = std::log(det3(B) / det3(A));
+    const float det_term = std::log(detB / detA);
     return 0.5f * (trace_term + dot(d, Bd) - 3.0f + det_term);
 }
 }  // namespace lod_detail
@@ -539,6 +544,9 @@ public:
         kid[0].assign(n, NONE); kid[1].assign(n, NONE);
         err.assign(n, 0.0f); level.assign(n, 0u); wt.resize(n);
         for (uint32_t i = 0; i < n; ++i) wt[i] = splats[i].weight();
+        cov_det.clear(); cov_inv.clear();
+        cov_det.reserve(2 * static_cast<size_t>(n)); cov_inv.reserve(2 * static_cast<size_t>(n));
+        for (uint32_t i = 0; i < n; ++i) remember_cov(splats[i]);
         // active set: index-linked list in insertion order; slot 2n-1 nodes at most, sentinel = `cap`
         const uint32_t cap = n ? 2 * n - 1 : 0;
         std::vector<uint32_t> next(cap + 1), prev(cap + 1);
@@ -580,6 +588,7 @@ public:
             err.push_back(top.error);
             level.push_back(std::max(level[top.a], level[top.b]) + 1u);
             wt.push_back(splats[id].weight());
+            remember_cov(splats[id]);
             merged_away[top.a] = merged_away[top.b] = 1;
             unlink(top.b); unlink(top.a);
             others.clear();
@@ -594,6 +603,8 @@ public:
         }
         root_ids.clear();
         for (uint32_t x = next[cap]; x != cap; x = next[x]) root_ids.push_back(x);
+        std::vector<float>().swap(cov_det);             // (only the build needs them)
+        std::vector<lod_detail::Cov3>().swap(cov_inv);
     }
 
     // HC.cpp:100-132.  The reference erases the examined entry and appends its two children, which is a first-in
@@ -658,8 +669,30 @@ private:
         const float total = wa + wb;
         wa /= total; wb /= total;
         const Splat c = merge_splats(splats[a], splats[b], wa, wb);
-        return wa * splat_divergence(splats[a], c) + wb * splat_divergence(splats[b], c);
+        // = wa * splat_divergence(splats[a], c) + wb * splat_divergence(splats[b], c) (Splat.h:169-195) with what depends on one
+        // node only (its covariance's determinant and inverse) taken from the per-node cache and the merged splat's computed once
+        using namespace lod_detail;
+        const Cov3 C = cov_of(c);
+        const float detC = det3(C);
+        const Cov3 Ci = inv3_det(C, detC);
+        const vec3 pc = xyz(c.transform[3]);
+        auto divergence = [&](uint32_t x) {
+            const Splat& sx = splats[x];
+            const Cov3 X = cov_of(sx);
+            const vec3 px = xyz(sx.transform[3]);
+            const float kl = 0.5f * (kl_term_pre(X, px, cov_det[x], Ci, detC, pc) + kl_term_pre(C, pc, detC, cov_inv[x], cov_det[x], px));
+            const vec4 cd = sx.color - c.color;
+            return kl + length(xyz(cd)) + std::fabs(sx.color.w - c.color.w);
+        };
+        return wa * divergence(a) + wb * divergence(b);
     }
+    void remember_cov(const Splat& s) {
+        const lod_detail::Cov3 X = lod_detail::cov_of(s);
+        cov_det.push_back(lod_detail::det3(X));
+        cov_inv.push_back(lod_detail::inv3_det(X, cov_det.back()));
+    }
+    std::vector<float> cov_det;                        // per node: det and inverse of its covariance (pair_error)
+    std::vector<lod_detail::Cov3> cov_inv;
     std::vector<uint32_t> kid[2], level, root_ids;
     std::vector<float> err, wt;
 };
