@@ -860,8 +860,9 @@ int gsx_set_framebuffer_dev(gsx_ctx* c, void* rgba8_dev, uint64_t capacity_bytes
 
 // Page-locked frames for synchronous readers (include/gsx.h).  The set remembers which pointers hipHostMalloc gave out, so a
 // block that had to come from malloc is released the right way too.
-static std::mutex g_pinned_mu;
-static std::unordered_set<void*> g_pinned;
+// (both live until the process ends: a frame released from a static destructor still finds them)
+static std::mutex& g_pinned_mu = *new std::mutex;
+static std::unordered_set<void*>& g_pinned = *new std::unordered_set<void*>;
 
 void* gsx_host_alloc_pinned(uint64_t bytes) {
     if (bytes == 0) bytes = 1;

@@ -936,3 +936,21 @@ def test_random_call_sequences_with_sort_ahead(pkg, oracle, synth, seed):
         assert frames >= 20, frames
     finally:
         fast.close(); strict.close(); tree.close()
+
+
+def test_render_into_pinned_frame_matches(gsx, pkg, synth, oracle):
+    """Gsx.render(out=pinned_frame): the same bytes as into an ordinary array (the read-back goes by DMA into page-locked memory)."""
+    cam = __import__("importlib").import_module("gaussian_splatting_amd.camera")
+    splats = oracle.raw_to_splat(synth.clustered_cloud(30000, seed=41), center=True)
+    gsx.upload(splats)
+    w, h = 320, 200
+    pin = pkg.pinned_frame(h, w)
+    for az in (0.3, 1.7):
+        world = cam.orbit_world(4.0, az, 0.2)
+        view, proj, pos = cam.camera_matrices(world, 45.0, w / h)
+        u = pkg.make_uniforms(proj, view)
+        gsx.sort(pos, download=False)
+        ref = gsx.render(u, w, h)
+        gsx.sort(pos, download=False)
+        got = gsx.render(u, w, h, out=pin)
+        assert got is pin and np.array_equal(ref, pin) and pin[..., :3].std() > 3

@@ -362,3 +362,16 @@ def test_pinned_host_memory_falls_back_without_a_gpu(pkg):
         assert buf[max(nbytes, 1) - 1] == 9
         lib.gsx_host_free_pinned(p)
     lib.gsx_host_free_pinned(None)
+
+
+def test_pinned_frame_array(pkg):
+    import gc
+    a = pkg.pinned_frame(37, 53)
+    assert a.shape == (37, 53, 4) and a.dtype == np.uint8 and a.flags.writeable and not a.any()
+    a[3, 5] = (1, 2, 3, 4)
+    v = a[3:4]
+    del a
+    gc.collect()
+    assert tuple(v[0, 5]) == (1, 2, 3, 4)          # a view keeps the memory alive
+    del v
+    gc.collect()
