@@ -273,6 +273,10 @@ int gsx_set_option(gsx_ctx* c, const char* name, uint64_t value) {
         // frame (sort k+1, render k, sort k+2, render k+1 ...); setting the option forgets permutations that wait to be drawn
         c->opt_sort_ahead = value ? 1 : 0;
         c->undrawn = 0;
+    } else if (!std::strcmp(name, "deferred_readback")) {
+        int rc = set_device(c);
+        if (rc || (rc = gsx_frame_finish(c))) return rc;     // (frames queued under the old rule are delivered first)
+        c->opt_deferred_readback = value ? 1u : 0u;
     } else if (!std::strcmp(name, "frames_in_flight")) {
         if (value < 1 || value > 2) { c->err = "frames_in_flight must be 1 or 2"; return GSX_E_INVALID; }
         int rc = set_device(c);
@@ -780,7 +784,8 @@ int gsx_render(gsx_ctx* c, const gsx_uniforms* u, uint32_t width, uint32_t heigh
     if (rc) return rc;
     double dbg_t1 = 0.0;
     struct DbgExit { double t0; double* t1; ~DbgExit() { if (g_dbg_host) fprintf(stderr, "[host] render %.1f wait-done %.1f .. %.1f\n", t0, *t1, gsx_dbg_now()); } } dbg_exit{g_dbg_host ? gsx_dbg_now() : 0.0, &dbg_t1};
-    if (c->opt_frames_in_flight >= 2 && !c->profiling && c->parked.fstream) {
+    const bool two_slots = c->opt_frames_in_flight >= 2 && !c->profiling && c->parked.fstream;
+    if (two_slots) {
         // two frames in flight: this frame takes the slot of the frame before the last one (long finished, as a rule) and is
         // queued beside the last one, which the host does not wait for
         if (c->frame_pending) gsx_slot_switch(c);
@@ -803,6 +808,15 @@ int gsx_render(gsx_ctx* c, const gsx_uniforms* u, uint32_t width, uint32_t heigh
     if (c->fstream == c->stream && behind_latest) c->sort_join_pending = false;
     if ((rc = gsx_launch_render(c, u, width, height, y0, y1))) return rc;
     c->ev_recorded[EV_RAST1] = c->profiling;
+    if (rgba8_out_host && c->opt_deferred_readback && two_slots) {
+        // deferred read-back: the frame stays queued; its pixels are copied out when its slot is finished - by the call after
+        // the next one, or by gsx_sync - while the frame queued in between runs on the device
+        const uint64_t row = static_cast<uint64_t>(width) * 4;
+        c->rb_dst = static_cast<uint8_t*>(rgba8_out_host);
+        c->rb_off = y0 * row;
+        c->rb_bytes = (y1 - y0) * row;
+        return GSX_OK;
+    }
     if (rgba8_out_host) {
         if ((rc = check_flags(c))) return rc;
         const uint64_t row = static_cast<uint64_t>(width) * 4;

@@ -137,6 +137,8 @@ struct GsxFrameSlot {
     uint8_t* fb = nullptr;             // RGBA8 width*height (the library's own framebuffer of this slot)
     uint64_t fb_cap = 0;
     uint8_t* fb_cur = nullptr;         // where the slot's queued / last frame was rendered
+    uint8_t* rb_dst = nullptr;         // option deferred_readback: host buffer the slot's queued frame is copied into once it is finished
+    uint64_t rb_off = 0, rb_bytes = 0;
     uint32_t fb_w = 0, fb_h = 0;
     uint32_t* pair_ws = nullptr;       // radix workspace of the pair sort
     uint64_t pair_ws_words = 0;
@@ -323,6 +325,7 @@ struct gsx_ctx : GsxFrameSlot {
     hipEvent_t ev_perm[GSX_PERM_RING] = {};   // end of the sort that filled ring slot b (recorded with sort_ahead)
     bool perm_rec[GSX_PERM_RING] = {};
     uint64_t opt_frames_in_flight = 2;
+    uint32_t opt_deferred_readback = 0;             // gsx_render(..., host buffer) queues the frame and returns; the pixels arrive when the slot is finished
     uint32_t opt_sample_whole_every = 2;            // ... and every how many SAMPLES one brackets keys + sort as a whole instead of its launches
     uint32_t opt_sample_every = GSX_SAMPLE_EVERY;   // profiling level 2: every how many sorts one is a sampled (synchronous) one
     bool sort_join_pending = false;      // a sort was queued on sort_stream and the main stream has not waited for it yet

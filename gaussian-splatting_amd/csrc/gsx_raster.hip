@@ -1308,7 +1308,23 @@ int gsx_frame_finish_touching(gsx_ctx* c, const uint8_t* lo, const uint8_t* hi) 
     return rc;
 }
 
+static int frame_finish_active_impl(gsx_ctx* c);
+
+// Completes the active slot's queued frame (more iterations if it needs them), then - option deferred_readback - copies it into
+// the host buffer its gsx_render call named.  The copy runs on the slot's own stream, which is idle by then, so the other
+// slot's frame keeps running beside it.
 int gsx_frame_finish_active(gsx_ctx* c) {
+    const bool was_pending = c->frame_pending;
+    const int rc = frame_finish_active_impl(c);
+    uint8_t* dst = c->rb_dst;
+    c->rb_dst = nullptr;
+    if (rc != GSX_OK || !was_pending || !dst || !c->fb_cur) return rc;
+    GSX_HIP(c, hipMemcpyAsync(dst + c->rb_off, c->fb_cur + c->rb_off, c->rb_bytes, hipMemcpyDeviceToHost, c->fstream));
+    GSX_HIP(c, hipStreamSynchronize(c->fstream));
+    return GSX_OK;
+}
+
+static int frame_finish_active_impl(gsx_ctx* c) {
     if (!c->frame_pending) return GSX_OK;
     GSX_HIP(c, hipEventSynchronize(c->frame_ev));
     GsxFrameState& f = c->frame;

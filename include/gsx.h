@@ -148,6 +148,12 @@ int gsx_get_sort_samples(gsx_ctx* ctx, double* sum_ms, uint32_t* sorts, int rese
  *                   the option, to either value, forgets permutations that wait to be drawn (the latest one stays current).
  *   "frames_in_flight"  1 = wait for frame k before queuing frame k + 1 (default 2: frame k + 1 is binned and rasterized on a
  *                   second frame slot while frame k is still running; same pixels)
+ *   "deferred_readback"  1 = gsx_render with a host buffer queues the frame and returns at once; the pixels of call k are in its
+ *                   buffer when call k + 2 returns (its slot is taken over then), or after gsx_sync, and the buffer must stay
+ *                   valid until then (page-locked memory, gsx_host_alloc_pinned, keeps the copy a plain DMA).  A viewer that
+ *                   can show a frame two calls late keeps both frame slots busy although every frame is read back.  Default 0:
+ *                   gsx_render returns with the pixels.  Needs frames_in_flight 2 and profiling off or sampled; otherwise the
+ *                   call is the synchronous one.  Setting the option delivers what is queued first.
  *   "tile_caps"     0 = bin every live tile through the whole window (default 1: a tile is binned only up to 1.5 x the depth
  *                   at which it saturated in the frame slot's last frame, when the picture has moved by at most a few tiles
  *                   since - exactly up to that depth when view and shading uniforms are unchanged; a tile that does not saturate after

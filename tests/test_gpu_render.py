@@ -954,3 +954,45 @@ def test_render_into_pinned_frame_matches(gsx, pkg, synth, oracle):
         gsx.sort(pos, download=False)
         got = gsx.render(u, w, h, out=pin)
         assert got is pin and np.array_equal(ref, pin) and pin[..., :3].std() > 3
+
+
+def test_deferred_readback_delivers_each_frame_two_calls_late(pkg, synth, oracle):
+    """Option deferred_readback: gsx_render(host buffer) returns at once and the frame of call k is in ITS buffer when call k + 2
+    returns, or after gsx_sync; the bytes are those of the synchronous call."""
+    cam = __import__("importlib").import_module("gaussian_splatting_amd.camera")
+    splats = oracle.raw_to_splat(synth.clustered_cloud(60000, seed=43), center=True)
+    w, h = 400, 240
+    g = pkg.Gsx(0)
+    try:
+        g.upload(splats)
+        poses = []
+        for k in range(7):
+            world = cam.orbit_world(4.0, 0.35 * k, 0.1 * k)
+            view, proj, pos = cam.camera_matrices(world, 45.0, w / h)
+            poses.append((pos, pkg.make_uniforms(proj, view, bayerSize=(2 if k == 4 else 1))))
+        refs = []
+        for pos, u in poses:
+            g.sort(pos, download=False)
+            refs.append(g.render(u, w, h).copy())
+        assert len({r.tobytes() for r in refs}) == len(refs)
+        g.set_option("deferred_readback", 1)
+        ring = [pkg.pinned_frame(h, w) for _ in range(3)]
+        for b in ring:
+            b[...] = 77
+        for k, (pos, u) in enumerate(poses):
+            g.sort(pos, download=False)
+            g.render(u, w, h, out=ring[k % 3])
+            if k >= 2:
+                assert np.array_equal(ring[(k - 2) % 3], refs[k - 2]), k
+        g.sync()
+        assert np.array_equal(ring[5 % 3], refs[5]) and np.array_equal(ring[6 % 3], refs[6])
+        # a band: only its rows are written
+        ring[0][...] = 77
+        g.sort(poses[1][0], download=False)
+        g.render(poses[1][1], w, h, 48, 112, out=ring[0])
+        g.set_option("deferred_readback", 0)                       # delivers what is queued
+        assert np.array_equal(ring[0][48:112], refs[1][48:112]) and np.all(ring[0][:48] == 77) and np.all(ring[0][112:] == 77)
+        g.sort(poses[2][0], download=False)
+        assert np.array_equal(g.render(poses[2][1], w, h), refs[2])   # synchronous again
+    finally:
+        g.close()
