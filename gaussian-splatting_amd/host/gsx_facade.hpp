@@ -148,11 +148,25 @@ enum class ErrorType { NoError, Validation, OutOfMemory, Internal, Unknown, Devi
 using ErrorCallback = std::function<void(ErrorType, const char*)>;   // webgpu.hpp's ErrorCallback
 // The swap chain of renderer.cpp:73-95,123-151: one RGBA8 frame in host memory that render() fills by readback.
 // present() hands it to `onPresent` (the optional viewer front end blits it); headless it is a no-op.
+// With Renderer::setDeferredPresent(true) it is a ring of three such frames, like a swap chain with images in flight:
+// render() queues frame k into ring[k % 3] and returns, and the present() of loop k + 2 shows frame k, which the library has
+// delivered by then (gsx option deferred_readback); Renderer::finishPresent() shows the last two.
 struct Surface {
     std::shared_ptr<FrameBytes> frame;
     uint32_t width = 0, height = 0;
     std::function<void(const uint8_t* rgba8, uint32_t width, uint32_t height)> onPresent;
-    void present() const { if (onPresent && frame) onPresent(frame->data(), width, height); }   // main.cpp:282
+    std::vector<std::shared_ptr<FrameBytes>> ring;     // deferred presentation: the frames in flight (empty = synchronous)
+    uint64_t queued = 0, shown = 0;                    // frames handed to render passes / to onPresent
+    void present() {                                   // main.cpp:282
+        if (ring.empty()) { if (onPresent && frame) onPresent(frame->data(), width, height); return; }
+        ++queued;
+        if (queued - shown > 2) show_next();
+    }
+    void show_next() {
+        frame = ring[shown % ring.size()];
+        ++shown;
+        if (onPresent) onPresent(frame->data(), width, height);
+    }
     void unconfigure() {}
     void release() { frame.reset(); }
     explicit operator bool() const { return static_cast<bool>(frame); }
@@ -241,8 +255,25 @@ public:
         if (!surface) return v;                                   // (the reference returns nullptr when the surface has no texture)
         v.width = surface.width;
         v.height = surface.height;
-        v.pixels = surface.frame;
+        v.pixels = surface.ring.empty() ? surface.frame : surface.ring[surface.queued % surface.ring.size()];
         return v;
+    }
+    // Pipelined presentation for front ends that can show a frame two loops late (see Surface): both of the library's frame
+    // slots stay busy although every frame is read back.  Off (the default), present() shows the frame just rendered.
+    void setDeferredPresent(bool on) {
+        if (!device) throw std::runtime_error("Renderer::setDeferredPresent before init");
+        finishPresent();
+        gsx_check(device.ctx.get(), gsx_set_option(device.ctx.get(), "deferred_readback", on ? 1 : 0), "gsx_set_option(deferred_readback)");
+        surface.ring.clear();
+        surface.queued = surface.shown = 0;
+        if (on)
+            for (int i = 0; i < 3; ++i) surface.ring.push_back(std::make_shared<FrameBytes>(static_cast<size_t>(width) * height * 4));
+    }
+    // Delivers and shows the frames still in flight (deferred presentation; a no-op otherwise).
+    void finishPresent() {
+        if (surface.ring.empty() || !device) return;
+        gsx_check(device.ctx.get(), gsx_sync(device.ctx.get()), "gsx_sync");
+        while (surface.shown < surface.queued) surface.show_next();
     }
     RenderPassEncoder create_render_pass_encoder(TextureView& targetView, CommandEncoder&) {  // renderer.cpp:153-176
         RenderPassEncoder p;

@@ -136,7 +136,11 @@ public:
     std::function<void(const uint8_t* rgba8, uint32_t w, uint32_t h, uint64_t frame)> onFrame;   // behind surface.present()
     std::FILE* log = stderr;
     uint32_t statsEvery = 60;              // frames between two statistics lines (0 = none)
+    bool pipelined = false;                // present every frame two loops late and keep both frame slots busy (Renderer::setDeferredPresent)
+    ViewerUniforms presentedUniforms;      // inside onFrame: the uniform block and camera of the frame being presented
+    mat4 presentedWorld{1.0f};
     uint64_t framesPresented = 0;
+    uint64_t framesRendered = 0;           // (ahead of framesPresented by up to two when pipelined)
 
     GUI gui;
     FrameClock imGuiIo;                    // (gui.imGuiIo in the reference)
@@ -156,13 +160,20 @@ public:
         InitializeBuffers();
         InitializeScene();
         m_renderer.surface.onPresent = [this](const uint8_t* px, uint32_t w, uint32_t h) {
+            if (!inFlight.empty()) {
+                presentedUniforms = inFlight.front().first;
+                presentedWorld = inFlight.front().second;
+                inFlight.pop_front();
+            }
             if (onFrame) onFrame(px, w, h, framesPresented);
             ++framesPresented;
         };
+        if (pipelined) m_renderer.setDeferredPresent(true);
         return true;
     }
 
     void Terminate() {                                                            // main.cpp:203-207
+        m_renderer.finishPresent();                                               // (pipelined: the last two frames)
         pipeline.release();
         glfwDestroyWindow(m_window);
         m_window = nullptr;
@@ -207,14 +218,16 @@ public:
         command.release();
         drawnInstances = renderPass.drawnInstances;
         targetView.release();
+        inFlight.emplace_back(uniforms, camera->worldMatrix);
+        ++framesRendered;
         m_renderer.surface.present();                                             // main.cpp:282
         m_renderer.device.poll(false);
-        if (statsEvery && log && framesPresented % statsEvery == 0 && imGuiIo.Framerate > 0.0) {
+        if (statsEvery && log && framesRendered % statsEvery == 0 && imGuiIo.Framerate > 0.0) {
             const uint32_t* sorted = nullptr;           // (the draw records the selection's capacity; the cut's size is asked for only here)
             uint32_t drawn = drawnInstances;
             if (gsx_get_sorted_dev(m_renderer.device.ctx.get(), &sorted, &drawn) != GSX_OK) drawn = drawnInstances;
             std::fprintf(log, "%.3f ms/frame (%.1f FPS)  frame %llu  %u splats drawn\n", 1000.0 / imGuiIo.Framerate, imGuiIo.Framerate,   // gui.cpp:130-131
-                         static_cast<unsigned long long>(framesPresented), drawn);
+                         static_cast<unsigned long long>(framesRendered), drawn);
         }
     }
 
@@ -286,6 +299,7 @@ private:
     RenderPipeline pipeline;
     BindGroup bindGroup;
     Buffer transformBuffer;
+    std::deque<std::pair<ViewerUniforms, mat4>> inFlight;   // frames rendered and not presented yet
     uint64_t idleFrames = 0;
     bool shouldClose = false;
 };

@@ -3,7 +3,7 @@
 // a raw RGBA8 stream, with the window's events read from a script (a file, or stdin / a FIFO a remote front end feeds).
 //
 //   gsx_view scene.splat|scene.ply [--mesh base|octree|hc|gridhc] [--size WxH] [--gpu N] [--events FILE|-]
-//            [--frames N] [--out DIR] [--raw FILE|-] [--every N] [--uniforms FILE] [--stats N] [--no-center]
+//            [--frames N] [--out DIR] [--raw FILE|-] [--every N] [--uniforms FILE] [--stats N] [--no-center] [--pipelined]
 //
 //   --events   the event script (see gsx_viewer.hpp); without it the camera rests and --frames frames are rendered
 //   --frames   stop after N presented frames (default: until the script ends; 1 without a script)
@@ -11,6 +11,7 @@
 //   --raw      file / FIFO / - (stdout) that receives width*height*4 bytes per frame, e.g.
 //              gsx_view s.splat --size 1280x720 --events ev.txt --raw - | ffplay -f rawvideo -pixel_format rgba -video_size 1280x720 -
 //   --uniforms appends the 224-byte uniform block and the camera's 64-byte world matrix of every presented frame
+//   --pipelined  present every frame two loops late; both of the library's frame slots stay busy (about a third more frames per second)
 //   --stats    frames between two "ms/frame (FPS)" lines on stderr (gui.cpp:130-131; default 60, 0 = none)
 #include <cstdlib>
 #include <cstring>
@@ -27,7 +28,7 @@ struct Options {
     int w = 1000, h = 800, gpu = 0;                  // main.cpp:101-102
     uint64_t frames = 0, every = 1;
     uint32_t stats = 60;
-    bool center = true;
+    bool center = true, pipelined = false;
 };
 
 template <typename Mesh>
@@ -39,6 +40,7 @@ static int run(const Options& o) {
     app.height = static_cast<float>(o.h);
     app.gpu = o.gpu;
     app.statsEvery = o.stats;
+    app.pipelined = o.pipelined;
     std::ifstream script;
     if (o.events == "-") app.events = &std::cin;
     else if (!o.events.empty()) {
@@ -56,14 +58,14 @@ static int run(const Options& o) {
     app.onFrame = [&](const uint8_t* px, uint32_t w, uint32_t h, uint64_t frame) {
         sink(px, w, h, frame);
         if (uni) {
-            uni.write(reinterpret_cast<const char*>(&app.uniforms), sizeof app.uniforms);
-            uni.write(reinterpret_cast<const char*>(app.camera->worldMatrix.data()), 64);
+            uni.write(reinterpret_cast<const char*>(&app.presentedUniforms), sizeof app.presentedUniforms);
+            uni.write(reinterpret_cast<const char*>(app.presentedWorld.data()), 64);
         }
     };
     if (!app.Initialize()) return 1;                                              // main.cpp:113-115
     std::fprintf(stderr, "gsx_view: %zu splats, %d x %d, mesh %s\n", app.splatMesh.splatData.size(), o.w, o.h, o.mesh.c_str());
     const uint64_t limit = o.frames ? o.frames : (app.events ? std::numeric_limits<uint64_t>::max() : 1u);
-    while (app.IsRunning() && app.framesPresented < limit) app.MainLoop();        // main.cpp:128-131
+    while (app.IsRunning() && app.framesRendered < limit) app.MainLoop();         // main.cpp:128-131
     app.Terminate();                                                              // main.cpp:134
     if (sink.raw && sink.raw != stdout) std::fclose(sink.raw);
     std::fprintf(stderr, "gsx_view: %llu frames presented\n", static_cast<unsigned long long>(app.framesPresented));
@@ -89,12 +91,13 @@ int main(int argc, char** argv) {
         else if (a == "--uniforms") o.uniforms = value();
         else if (a == "--stats") o.stats = static_cast<uint32_t>(std::strtoul(value(), nullptr, 10));
         else if (a == "--no-center") o.center = false;
+        else if (a == "--pipelined") o.pipelined = true;
         else if (a[0] == '-' && a != "-") { std::fprintf(stderr, "gsx_view: unknown option %s\n", a.c_str()); return 2; }
         else o.scene = a;
     }
     if (o.scene.empty()) {
         std::fprintf(stderr, "usage: gsx_view scene.splat|scene.ply [--mesh base|octree|hc|gridhc] [--size WxH] [--gpu N] [--events FILE|-] [--frames N]\n"
-                             "                [--out DIR] [--raw FILE|-] [--every N] [--uniforms FILE] [--stats N] [--no-center]\n");
+                             "                [--out DIR] [--raw FILE|-] [--every N] [--uniforms FILE] [--stats N] [--no-center] [--pipelined]\n");
         return 2;
     }
     try {

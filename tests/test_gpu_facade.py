@@ -205,6 +205,14 @@ def test_viewer_front_end(tmp_path, pkg, synth, oracle):
         assert rawf[..., :3].std() > 3
     finally:
         g.close()
+    # pipelined presentation (every frame shown two loops late, both frame slots busy): the same frames and records in the same order
+    r = subprocess.run([exe, str(scene), "--size", f"{W}x{H}", "--events", str(tmp_path / "ev.txt"), "--raw", str(tmp_path / "raw2.rgba"),
+                        "--uniforms", str(tmp_path / "uni2.bin"), "--stats", "0", "--pipelined"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and f"{len(frames)} frames presented" in r.stderr, r.stdout + r.stderr
+    assert open(tmp_path / "raw2.rgba", "rb").read() == open(tmp_path / "raw.rgba", "rb").read()
+    assert open(tmp_path / "uni2.bin", "rb").read() == open(tmp_path / "uni.bin", "rb").read()
+    r = subprocess.run([exe, str(scene), "--size", f"{W}x{H}", "--frames", "1", "--pipelined", "--raw", str(tmp_path / "one.rgba")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "1 frames presented" in r.stderr and np.array_equal(np.fromfile(tmp_path / "one.rgba", np.uint8), rawf[0].reshape(-1))
     # an LOD mesh through the same loop (the reference's choice, main.cpp:98, is GridHC), events from a pipe, no script file
     r = subprocess.run([exe, str(scene), "--mesh", "octree", "--size", f"{W}x{H}", "--events", "-", "--raw", str(tmp_path / "oct.rgba"), "--stats", "0"],
                        input="set min_screen_area 1\nframe\nmove 0 0\nbutton 0 1\nmove 30 0\nframe\n", capture_output=True, text=True, timeout=300)

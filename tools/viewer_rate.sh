@@ -19,5 +19,7 @@ PY
 for mesh in base octree; do
     timeout -k 10 600 gaussian-splatting_amd/gsx_view $out/scene.splat --mesh $mesh --size 1920x1080 --events $out/drag.txt --stats 60 2> $out/rate_$mesh.txt
     tail -4 $out/rate_$mesh.txt
+    timeout -k 10 600 gaussian-splatting_amd/gsx_view $out/scene.splat --mesh $mesh --size 1920x1080 --events $out/drag.txt --stats 60 --pipelined 2> $out/rate_${mesh}_pipelined.txt
+    tail -4 $out/rate_${mesh}_pipelined.txt
 done
 rm -f $out/scene.splat
