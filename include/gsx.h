@@ -255,7 +255,8 @@ int gsx_get_keys(gsx_ctx* ctx, const float cam_pos[3], float* dist_out_host, uin
  * that call also runs the on-demand iterations a heavy frame may still need.
  * Up to two queued frames are in flight at a time, on two streams (the call
  * waits on the host only for the frame BEFORE the last one, whose slot it
- * takes).  A frame is a pure function of (scene, permutation, uniforms):
+ * takes).  With the option "deferred_readback" a call WITH a host buffer is queued the same way and the buffer is filled when
+ * the frame's slot is taken over (by the call after the next one) or at gsx_sync.  A frame is a pure function of (scene, permutation, uniforms):
  * neither the iteration schedule nor what else runs beside it changes a byte. ---- */
 int gsx_render(gsx_ctx* ctx, const gsx_uniforms* u, uint32_t width, uint32_t height,
                uint32_t y0, uint32_t y1, void* rgba8_out_host);
