@@ -362,6 +362,7 @@ def main():
 
     pose_no = 0
     last_pose = [None]
+    rb_ring = [None]    # set by the read-back extra
 
     # Sort ahead (library option sort_ahead): the step queues the sort of the NEXT pose, then this pose's frame, which draws the
     # permutation its own pose was sorted for one step earlier.  Every step is still one sort and one frame of a new pose; what
@@ -425,7 +426,10 @@ def main():
                     if bg is not None:
                         g.stream()                                     # (orders the main stream, where torch gathers, behind the frames queued so far)
                     batcher.frame_done(frame_no - 1)                   # closes a batch every gather_batch frames
-            g.render(uni, W, H, download=False)
+            if rb_ring[0] is not None:      # (extras only: every frame read back, deferred, into a ring of page-locked frames)
+                g.render(uni, W, H, out=rb_ring[0][frame_no % 3])
+            else:
+                g.render(uni, W, H, download=False)
         frame_no += 1
 
     def drain():
@@ -586,6 +590,23 @@ def main():
             extras["ms_per_step_unsampled"] = (time.perf_counter() - t1) / max(a.steps, 1) * 1e3
             extras["unsampled_note"] = ("the headline's workload (a new pose every step, continuing along the orbit) and the no-history figure with "
                                         "profiling level 0: no sort of the loop carries events; `value` keeps the instrumented time")
+            # the PCIe-inclusive figure: the same loop with EVERY frame read back into host memory (8.3 MB at 1080p), by the
+            # deferred read-back (the pixels of call k arrive while frame k + 1 runs) into a ring of three page-locked frames
+            if fg is None and bg is None:
+                g.set_option("deferred_readback", 1)
+                rb_ring[0] = [pkg.pinned_frame(H, W) for _ in range(3)]
+                for i in range(3):
+                    step()
+                g.sync()
+                t1 = time.perf_counter()
+                for i in range(a.steps):
+                    step()
+                g.sync()
+                extras["ms_per_step_with_readback"] = (time.perf_counter() - t1) / max(a.steps, 1) * 1e3
+                extras["readback_note"] = ("the unsampled loop with every frame copied to host memory (PCIe-inclusive; option deferred_readback, "
+                                           "page-locked ring of three frames); never `value`: the headline's frames stay in HBM")
+                rb_ring[0] = None
+                g.set_option("deferred_readback", 0)
             g.set_profiling(2)
         # stage breakdown on a few extra frames with every stage bracketed (outside the timed region)
         g.set_profiling(1)
